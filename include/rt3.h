@@ -1,0 +1,207 @@
+/* rt3.h — C ABI of the MI355X-native render path (librt3hip.so).
+ *
+ * Drop-in boundary for the reference's per-pixel ray-trace loop.  The reference's own boundary is the
+ * C++ class RayTracer::Renderer (src/lib/renderer/Renderer.hpp:34-63: prerender() / render() /
+ * initialize_renderer()); the C++ mirror of that class lives in raytracer-3_amd/host/ and is a thin
+ * wrapper over the entry points declared here.  Everything below is plain pointers and sizes so that any
+ * FFI (ctypes, cgo, JNI ...) can bind it; INTEGRATION.md shows the binding a reference maintainer adds.
+ *
+ * Two render modes:
+ *   Mode R  ("reference mode")  rt3_render*      — exactly SequentialRenderer::render + ray_color
+ *            (src/lib/renderer/SequentialRenderer.cpp:47-109, 269-308): 1 primary ray per pixel,
+ *            brute-force nearest indexed triangle, flat baked face colour, sky gradient, RGBA8 pack.
+ *   Mode X  ("extension mode")  rt3_render_path* — analytic spheres, materials, spp, depth, counter-based
+ *            RNG, as sketched (never finished) by src/lib/shaders/raytracer/raytracer_v4.glsl and
+ *            random_v1.glsl; semantics are specified in DESIGN.md and restated on the CPU in oracle/.
+ *
+ * All functions returning int return 0 on success and a negative code on failure; the message is
+ * available from rt3_last_error().  Nothing here falls back to the CPU: without a HIP device every
+ * device entry point fails with RT3_E_DEVICE.
+ */
+#ifndef RT3_H
+#define RT3_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT3_E_ARG     (-1)   /* bad argument */
+#define RT3_E_DEVICE  (-2)   /* HIP runtime / device failure (includes "no device") */
+#define RT3_E_IO      (-3)   /* file could not be opened / parsed */
+#define RT3_E_STATE   (-4)   /* no scene set, etc. */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Wire structs
+ * ------------------------------------------------------------------------------------------------- */
+
+/* == RayTracer::GFace (src/lib/renderer/Vertex.hpp:39-51; GLSL std430 twin raytracer_v3.glsl:33-45).
+ * 48 bytes: u32 v1,v2,v3 @0/4/8; vec3 normal @16; vec3 color @32. */
+typedef struct rt3_gface {
+    uint32_t v1, v2, v3;
+    uint32_t _pad0;
+    float    normal[3];
+    uint32_t _pad1;
+    float    color[3];
+    uint32_t _pad2;
+} rt3_gface;
+
+/* == the four public vectors of RayTracer::Camera (src/lib/camera/Camera.hpp:27-34), i.e. the
+ * GCameraData block the Vulkan backend uploads (src/lib/renderer/VulkanRenderer.hpp:32-37). */
+typedef struct rt3_camera {
+    float origin[3];
+    float horizontal[3];
+    float vertical[3];
+    float lower_left_corner[3];
+} rt3_camera;
+
+/* Material kinds (Mode X).  RT3_MAT_FLAT is the only material the reference has: the hit returns the
+ * baked colour and the path ends (SequentialRenderer.cpp:101-103); it doubles as a diffuse emitter. */
+#define RT3_MAT_FLAT        0u   /* radiance += throughput * rgb ; path ends                     */
+#define RT3_MAT_LAMBERT     1u   /* rgb = albedo                                                  */
+#define RT3_MAT_METAL       2u   /* rgb = albedo, param = fuzz in [0,1]                           */
+#define RT3_MAT_DIELECTRIC  3u   /* param = index of refraction (rgb ignored, attenuation = 1)    */
+
+typedef struct rt3_material {
+    float    rgb[3];
+    float    param;
+    uint32_t kind;
+} rt3_material;
+
+#define RT3_FLAG_GAMMA2            1u   /* sqrt() each channel before packing (book gamma 2)           */
+#define RT3_FLAG_BLACK_BACKGROUND  2u   /* a miss contributes nothing (default: the reference's sky)    */
+
+/* Parameters of a Mode-X render.  tile_*: interleaved row-block sharding of the framebuffer
+ * (design intent: BlockInfo{x,y,w,h} of raytracer_v4.glsl:70-79).  Row-block b (tile_rows rows) belongs
+ * to shard (b mod tile_count); a shard renders only its own rows, into a compact buffer of
+ * rt3_rows_owned() rows.  tile_count = 1 renders the whole frame. */
+typedef struct rt3_params {
+    uint32_t width, height;      /* full frame */
+    uint32_t spp;                /* samples per pixel, >= 1 */
+    uint32_t max_depth;          /* ray casts per path, >= 1 (book "max_depth") */
+    uint32_t seed;
+    uint32_t flags;
+    float    lens_radius;        /* 0 = pinhole */
+    float    t_min;              /* self-intersection cut-off; book value 0.001 */
+    uint32_t tile_rows, tile_index, tile_count;
+} rt3_params;
+
+/* Counters of the last render on a context (device-side counts, HIP-event timings on the render stream). */
+typedef struct rt3_stats {
+    uint64_t ray_casts;          /* rays traced (primary + scattered)                                */
+    uint64_t prim_tests;         /* ray-primitive tests = ray_casts * (n_spheres + n_faces)          */
+    uint64_t samples;            /* pixels * spp rendered by this call                               */
+    float    trace_ms;           /* dominant kernel (trace / mode-R) duration, summed over launches  */
+    float    total_ms;           /* first launch -> last launch of the call (device time)            */
+    uint32_t launches;           /* launches of the dominant kernel                                  */
+    uint32_t n_spheres, n_faces;
+} rt3_stats;
+
+typedef struct rt3_ctx rt3_ctx;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Device context   (replaces the Vulkan Instance/GPU/MemoryPool bring-up of VulkanRenderer.cpp:43-94)
+ * ------------------------------------------------------------------------------------------------- */
+rt3_ctx*    rt3_create(int device_id);
+void        rt3_destroy(rt3_ctx* ctx);
+/* ctx may be NULL to read the error of a failed rt3_create(). */
+const char* rt3_last_error(const rt3_ctx* ctx);
+/* Optional: cap (bytes) for the per-sample radiance storage; more spp than fit are rendered in batches. */
+int         rt3_set_sample_storage_cap(rt3_ctx* ctx, uint64_t bytes);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Scene upload   (replaces Renderer::prerender's upload half: SequentialRenderer.cpp:174-195,246 /
+ *                 VulkanRenderer.cpp:210-261,355-387).  Replaces any previous scene of that kind.
+ * ------------------------------------------------------------------------------------------------- */
+/* faces/vertices are the merged arrays exactly as the reference keeps them (GFace[], vec4[] w=0).
+ * face_materials may be NULL: every face is then RT3_MAT_FLAT with its own GFace colour (Mode R). */
+int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces,
+                 const float* vertices_xyzw, uint32_t n_vertices,
+                 const rt3_material* face_materials);
+/* center_radius: 4 floats per sphere (cx,cy,cz,r), r > 0.  (Sphere{vec3 center; float radius; vec3 color},
+ * raytracer_v4.glsl:42-49.) */
+int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material* materials, uint32_t n);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Render   (replaces Renderer::render, Renderer.hpp:50)
+ * ------------------------------------------------------------------------------------------------- */
+/* Mode R, synchronous, host output: out_pixels[w*h] in the reference's word layout
+ * (0xFF | B<<8 | G<<16 | R<<24, row 0 = top; SequentialRenderer.cpp:297).  All rows are written; row h-1
+ * follows the GLSL twin (raytracer_v3.glsl:193-196) because the CPU loop never writes it. */
+int rt3_render(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint32_t height, uint32_t* out_pixels);
+/* Mode R, asynchronous on `stream` (a hipStream_t, may be NULL), device output buffer of w*h words. */
+int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint32_t height,
+                      void* d_out_pixels, void* stream);
+
+/* Mode X, synchronous, host output of rt3_rows_owned(params)*width words (compact tile rows). */
+int rt3_render_path(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* params, uint32_t* out_pixels);
+/* Mode X, asynchronous on `stream`, device output. */
+int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* params,
+                           void* d_out_pixels, void* stream);
+
+/* Rows of the frame owned by shard tile_index (see rt3_params), and the frame row of local row i. */
+uint32_t rt3_rows_owned(const rt3_params* params);
+uint32_t rt3_row_of_local(const rt3_params* params, uint32_t local_row);
+
+/* Waits for the last asynchronous render and fills `out` (may be called after the synchronous forms too). */
+int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Host-side scene API   (the step before the path: entities -> GFace[]/vec4[]; plain CPU code)
+ * ------------------------------------------------------------------------------------------------- */
+/* cpu_pre_render_triangle (src/lib/entities/Triangle.cpp:28-76): 1 face, 3 vertices (xyzw). */
+void     rt3_prerender_triangle(const float p1[3], const float p2[3], const float p3[3], const float color[3],
+                                rt3_gface* faces, float* vertices_xyzw);
+/* create_sphere counts (src/lib/entities/Sphere.cpp:101-102). */
+uint32_t rt3_sphere_face_count(uint32_t n_meridians, uint32_t n_parallels);
+uint32_t rt3_sphere_vertex_count(uint32_t n_meridians, uint32_t n_parallels);
+/* cpu_pre_render_sphere (src/lib/entities/Sphere.cpp:120-261). */
+void     rt3_prerender_sphere(const float center[3], float radius, uint32_t n_meridians, uint32_t n_parallels,
+                              const float color[3], rt3_gface* faces, float* vertices_xyzw);
+/* create_object's counting pass (src/lib/entities/Object.cpp:84-119). */
+int      rt3_object_count(const char* path, uint32_t* n_faces, uint32_t* n_vertices);
+/* cpu_pre_render_object (src/lib/entities/Object.cpp:131-199). */
+int      rt3_prerender_object(const char* path, const float center[3], float scale, const float color[3],
+                              rt3_gface* faces, uint32_t n_faces, float* vertices_xyzw, uint32_t n_vertices);
+/* SequentialRenderer::transfer_entity (SequentialRenderer.cpp:174-195): append with index rebasing.
+ * dst_* must have room; *dst_nf / *dst_nv are advanced. */
+void     rt3_transfer_entity(rt3_gface* dst_faces, uint32_t* dst_nf, float* dst_vertices_xyzw, uint32_t* dst_nv,
+                             const rt3_gface* faces, uint32_t nf, const float* vertices_xyzw, uint32_t nv);
+
+/* Camera::update (src/lib/camera/Camera.cpp:77-96). */
+void     rt3_camera_update(rt3_camera* cam, float focal_length, float viewport_width, float viewport_height);
+/* Extension (the reference camera cannot look-from/look-at): book camera, vfov in degrees. */
+void     rt3_camera_look_at(rt3_camera* cam, const float from[3], const float at[3], const float vup[3],
+                            float vfov_deg, float aspect, float focus_dist);
+
+/* Frame::to_ppm bytes (src/lib/camera/Frame.cpp:109-148): header + 3*w*h bytes.  Returns bytes written to
+ * `out` (capacity cap) or the required size when out == NULL. */
+uint64_t rt3_frame_ppm_bytes(const uint32_t* pixels, uint32_t width, uint32_t height, uint8_t* out, uint64_t cap);
+int      rt3_frame_to_ppm(const uint32_t* pixels, uint32_t width, uint32_t height, const char* path);
+
+/* Benchmark scenes (build-owned).  Each returns the sphere count written (<= cap) or, with
+ * NULL outputs, the count required.  All randomness comes from the reference's hash RNG
+ * (src/lib/shaders/random_v1.glsl:22-52) keyed by (seed, slot, dimension). */
+uint32_t rt3_scene_three_spheres(float* center_radius, rt3_material* materials, uint32_t cap);
+uint32_t rt3_scene_weekend(uint32_t seed, float* center_radius, rt3_material* materials, uint32_t cap);
+uint32_t rt3_scene_stress(uint32_t n, uint32_t seed, float* center_radius, rt3_material* materials, uint32_t cap);
+/* Cornell-style box tessellated into triangles (grid x grid quads per wall) with one emissive quad.
+ * Returns face count; vertices = 3 per face (unindexed).  NULL outputs -> counts only. */
+uint32_t rt3_scene_cornell(uint32_t grid, rt3_gface* faces, float* vertices_xyzw, rt3_material* face_materials,
+                           uint32_t cap_faces);
+
+/* Reference hash RNG, exported for known-answer tests (random_v1.glsl:22-52). */
+uint32_t rt3_hash_u32(uint32_t x);
+float    rt3_random_float(uint32_t m);
+
+/* Debug probe used by the parity tests only: element-wise DEVICE arithmetic on n inputs —
+ * div = a/b, sq = sqrt(|a|), fm = fma(a,b,a), (cs,sn) = sincos2pi(frac bits of a), sk3 = sky(a,b,-2) (3 per
+ * element), pk = pack(a,b,u).  Lets the tests prove the device's IEEE behaviour matches the host's. */
+int      rt3_debug_arith(rt3_ctx* ctx, const float* a, const float* b, uint32_t n, float* div, float* sq, float* fm,
+                         float* cs, float* sn, float* sk3, uint32_t* pk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT3_H */

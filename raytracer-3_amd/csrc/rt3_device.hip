@@ -1,0 +1,933 @@
+// rt3_device.hip — the render path on gfx950 (CDNA4): HIP kernels + the device half of the C ABI.
+//
+//   k_mode_r      Mode R: SequentialRenderer::render + ray_color (src/lib/renderer/SequentialRenderer.cpp:47-109,
+//                 269-308; GLSL twin src/lib/shaders/raytracer_v3.glsl:91-143,187-203).  One thread per pixel,
+//                 de-indexed faces staged through LDS in index order, IEEE arithmetic in the reference's order.
+//   k_trace       Mode X: the recursion of the (unfinished) raytracer_v4.glsl:187-290 flattened into an iterative
+//                 per-wavefront loop.  Every lane carries one path; each iteration traces all 64 paths of the
+//                 wave against LDS-staged primitive tiles, shades, and refills the lanes whose path ended with
+//                 fresh samples handed out by ballot + prefix-count (mbcnt), so waves stay full between bounces
+//                 without ever spilling ray state to HBM.  Finished samples land in a per-sample storage buffer
+//                 (SampleStorage of raytracer_v4.glsl:107-111) and are averaged in sample order by k_accumulate /
+//                 k_resolve (the reduce pass reduce_v1.glsl never got) — the image is bitwise independent of
+//                 scheduling, block size and GPU count.
+//
+// Compiled with -ffp-contract=off: a*b+c is two roundings unless written __builtin_fmaf.  Division and sqrt are
+// the correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), f32 denormals are kept.
+// No MFMA: the path is branchy scalar FP32; the bounding roofline is the FP32 vector ALU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt3.h"
+
+namespace {
+
+constexpr int      kBlock       = 256;     // 4 wavefronts of 64
+constexpr int      kCandSlots   = 16;      // deferred sphere candidates per lane (LDS), flushed when full
+constexpr uint32_t kWorkChunk   = 256;     // samples a wave takes from the global queue per atomic
+constexpr uint32_t kSphTileMax  = 1024;    // spheres per LDS tile (16 KiB)
+constexpr uint32_t kTriTileMax  = 256;     // faces per LDS tile (4 x float4 = 16 KiB)
+constexpr uint32_t kModeRTile   = 512;     // faces per LDS tile in k_mode_r (32 KiB)
+
+struct CamDev { float ox, oy, oz, hx, hy, hz, vx, vy, vz, lx, ly, lz; };
+
+// ------------------------------------------------------------------------------------------------------
+// Small device helpers
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// dot3 of SequentialRenderer.cpp:32-33 / glm::dot: unfused, left to right.
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return ax * bx + ay * by + az * bz;
+}
+// Mode-X dot: z*z' + (y*y' + x*x') as two fused multiply-adds.
+__device__ __forceinline__ float dotf(float ax, float ay, float az, float bx, float by, float bz) {
+    return fma_(az, bz, fma_(ay, by, ax * bx));
+}
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of a 64-bit lane mask below the calling lane (exclusive prefix count)
+__device__ __forceinline__ uint32_t prefix_count(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// random_v1.glsl:22-31, :37-52
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x += x << 10; x ^= x >> 6; x += x << 3; x ^= x >> 11; x += x << 15;
+    return x;
+}
+__device__ __forceinline__ uint32_t hash2(uint32_t a, uint32_t b) { return hash_u32(a ^ hash_u32(b)); }
+__device__ __forceinline__ float u01(uint32_t m) { return __uint_as_float((m & 0x007FFFFFu) | 0x3F800000u) - 1.0f; }
+__device__ __forceinline__ float rnd(uint32_t base, uint32_t ctr) { return u01(hash2(base, ctr)); }
+
+// sky gradient, SequentialRenderer.cpp:105-107 (float form of raytracer_v3.glsl:139-141; same bits)
+__device__ __forceinline__ void sky(float dx, float dy, float dz, float& r, float& g, float& b) {
+    const float len = __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+    const float uy = dy / len;
+    const float t = 0.5f * (uy + 1.0f);
+    const float a = 1.0f - t;
+    r = a * 1.0f + t * 0.5f;
+    g = a * 1.0f + t * 0.7f;
+    b = a * 1.0f + t * 1.0f;
+}
+// glm::packUnorm4x8(vec4(1, b, g, r)), glm/detail/func_packing.inl:67-83
+__device__ __forceinline__ uint32_t pack_channel(float c) {
+    float m = c < 0.0f ? 0.0f : c;
+    m = 1.0f < m ? 1.0f : m;
+    return (uint32_t)(__builtin_roundf(m * 255.0f)) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t pack_pixel(float r, float g, float b) {
+    return 0xFFu | (pack_channel(b) << 8) | (pack_channel(g) << 16) | (pack_channel(r) << 24);
+}
+
+// (cos, sin)(2*pi*u), u in [0,1): quadrant + Taylor/Horner in fma
+__device__ __forceinline__ void sincos2pi(float u, float& c_out, float& s_out) {
+    const float a = u * 4.0f;
+    const int k = (int)a;
+    const float f = a - (float)k;
+    const float x = f * 1.57079637f;
+    const float x2 = x * x;
+    float p = fma_(x2, -2.50521084e-8f, 2.75573192e-6f);
+    p = fma_(x2, p, -1.98412698e-4f);
+    p = fma_(x2, p, 8.33333333e-3f);
+    p = fma_(x2, p, -1.66666667e-1f);
+    const float s = fma_(x * x2, p, x);
+    float q = fma_(x2, 2.08767570e-9f, -2.75573192e-7f);
+    q = fma_(x2, q, 2.48015873e-5f);
+    q = fma_(x2, q, -1.38888889e-3f);
+    q = fma_(x2, q, 4.16666667e-2f);
+    q = fma_(x2, q, -0.5f);
+    const float c = fma_(x2, q, 1.0f);
+    const int kk = k & 3;
+    c_out = kk == 0 ? c : kk == 1 ? -s : kk == 2 ? -c : s;
+    s_out = kk == 0 ? s : kk == 1 ? c : kk == 2 ? -s : -c;
+}
+__device__ __forceinline__ void unit_vector(float xi0, float xi1, float& x, float& y, float& z) {
+    z = fma_(-2.0f, xi0, 1.0f);
+    const float rr = fma_(-z, z, 1.0f);
+    const float r = __builtin_sqrtf(rr > 0.0f ? rr : 0.0f);
+    float c, s;
+    sincos2pi(xi1, c, s);
+    x = r * c;
+    y = r * s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Mode R
+// ------------------------------------------------------------------------------------------------------
+// tri: 4 float4 per face — (n.xyz, n.p1), p1, p2, p3 — i.e. the reference's unused de-indexed Face struct
+// (src/lib/renderer/Vertex.hpp:24-36) with the plane distance of SequentialRenderer.cpp:67 precomputed.
+__global__ __launch_bounds__(kBlock) void k_mode_r(const float4* __restrict__ tri, const float4* __restrict__ face_rgb,
+                                                  uint32_t n_faces, CamDev cam, uint32_t width, uint32_t height,
+                                                  uint32_t* __restrict__ out) {
+    __shared__ float4 tile[kModeRTile * 4];
+    const uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = pixel < width * height;
+    const uint32_t x = valid ? pixel % width : 0u, y = valid ? pixel / width : 0u;
+
+    // SequentialRenderer.cpp:289-293 (u, v evaluated in double exactly as the C++ does, then rounded)
+    const float u = (float)((double)(float)x / ((double)(float)width - 1.0));
+    const float v = (float)((double)(float)(height - 1 - y) / ((double)(float)height - 1.0));
+    const float ox = cam.ox, oy = cam.oy, oz = cam.oz;
+    const float dx = ((cam.lx + u * cam.hx) + v * cam.vx) - ox;
+    const float dy = ((cam.ly + u * cam.hy) + v * cam.vy) - oy;
+    const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
+
+    uint32_t min_i = 0;
+    float min_t = __builtin_inff();                                 // (float)1e99, :52
+    for (uint32_t t0 = 0; t0 < n_faces; t0 += kModeRTile) {
+        const uint32_t cnt = min(kModeRTile, n_faces - t0);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < cnt * 4; k += kBlock) tile[k] = tri[(size_t)t0 * 4 + k];
+        __syncthreads();
+        if (!valid) continue;
+        for (uint32_t j = 0; j < cnt; j++) {                        // ascending face index == reference order
+            const float4 n = tile[4 * j];
+            const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);       // :56
+            if (nd == 0.0f) continue;
+            const float t = (dot3(n.x, n.y, n.z, ox, oy, oz) + n.w) / nd;      // :70 (sic: plus)
+            if (t < 0.0f || t >= min_t) continue;                   // :71
+            const float4 p1 = tile[4 * j + 1], p2 = tile[4 * j + 2], p3 = tile[4 * j + 3];
+            const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;  // :77
+            float ex, ey, ez, qx, qy, qz, cx, cy, cz;
+            ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+            ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+            ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+            min_i = t0 + j;
+            min_t = t;
+        }
+    }
+    if (!valid) return;
+    float r, g, b;
+    if (min_t < __builtin_inff()) { const float4 c = face_rgb[min_i]; r = c.x; g = c.y; b = c.z; }
+    else sky(dx, dy, dz, r, g, b);
+    out[pixel] = pack_pixel(r, g, b);                               // :297
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Mode X
+// ------------------------------------------------------------------------------------------------------
+struct TraceArgs {
+    const float4* sph;       const float* sph_invr;  const float4* sph_mat;  const uint32_t* sph_kind;  uint32_t n_sph;
+    const float4* tri;       const float4* tri_mat;  const uint32_t* tri_kind;                          uint32_t n_tri;
+    uint32_t sph_tile, tri_tile;
+    CamDev cam;
+    float lens_radius, lux, luy, luz, lvx, lvy, lvz;
+    uint32_t width, height, spp, max_depth, seed, flags, edge;
+    float t_min;
+    uint32_t tile_rows, tile_index, tile_count;
+    uint32_t npix;           // pixels owned by this shard
+    uint32_t s0;             // first sample of this batch
+    uint32_t total;          // npix * samples in this batch
+    float4* rad;             // per-sample radiance, [sample in batch][owned pixel]
+    uint32_t* work_counter;
+    unsigned long long* cast_counter;
+};
+
+struct Path {
+    float ox, oy, oz, dx, dy, dz;
+    float tr, tg, tb, lr, lg, lb;
+    uint32_t slot, base, depth;
+};
+
+__device__ __forceinline__ uint32_t frame_row(const TraceArgs& A, uint32_t local_row) {
+    if (A.tile_count <= 1) return local_row;
+    const uint32_t lb = local_row / A.tile_rows, in = local_row - lb * A.tile_rows;
+    return (lb * A.tile_count + A.tile_index) * A.tile_rows + in;
+}
+
+// sample -> primary ray (raytracer_v4.glsl:190-214 with the jitter in pixel units), unit direction
+__device__ __forceinline__ void start_path(const TraceArgs& A, uint32_t item, Path& P) {
+    const uint32_t sb = item / A.npix, pix = item - sb * A.npix;
+    const uint32_t s = A.s0 + sb;
+    const uint32_t lrow = pix / A.width, x = pix - lrow * A.width;
+    const uint32_t y = frame_row(A, lrow);
+    const uint32_t base = hash2(y * A.width + x, hash2(s, A.seed));
+    float jx = 0.0f, jy = 0.0f;
+    if (A.spp > 1) {
+        const float xi0 = rnd(base, 1), xi1 = rnd(base, 2);
+        if (A.edge != 0) {
+            const uint32_t sy = s / A.edge, sx = s - sy * A.edge;
+            jx = ((float)sx + xi0) / (float)A.edge - 0.5f;
+            jy = ((float)sy + xi1) / (float)A.edge - 0.5f;
+        } else { jx = xi0 - 0.5f; jy = xi1 - 0.5f; }
+    }
+    const float u = ((float)x + jx) / ((float)A.width - 1.0f);
+    const float v = ((float)(A.height - 1 - y) + jy) / ((float)A.height - 1.0f);
+    const CamDev& c = A.cam;
+    float rx = ((c.lx + u * c.hx) + v * c.vx) - c.ox;
+    float ry = ((c.ly + u * c.hy) + v * c.vy) - c.oy;
+    float rz = ((c.lz + u * c.hz) + v * c.vz) - c.oz;
+    float ox = c.ox, oy = c.oy, oz = c.oz;
+    if (A.lens_radius > 0.0f) {
+        const float xi2 = rnd(base, 3), xi3 = rnd(base, 4);
+        const float r = A.lens_radius * __builtin_sqrtf(xi2);
+        float cs, sn;
+        sincos2pi(xi3, cs, sn);
+        const float a = r * cs, b = r * sn;
+        const float fx = a * A.lux + b * A.lvx, fy = a * A.luy + b * A.lvy, fz = a * A.luz + b * A.lvz;
+        ox = ox + fx; oy = oy + fy; oz = oz + fz;
+        rx = rx - fx; ry = ry - fy; rz = rz - fz;
+    }
+    const float inv = 1.0f / __builtin_sqrtf(dot3(rx, ry, rz, rx, ry, rz));
+    P.ox = ox; P.oy = oy; P.oz = oz;
+    P.dx = rx * inv; P.dy = ry * inv; P.dz = rz * inv;
+    P.tr = P.tg = P.tb = 1.0f;
+    P.lr = P.lg = P.lb = 0.0f;
+    P.slot = item; P.base = base; P.depth = 0;
+}
+
+template <bool MULTI_TILE>
+__global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
+    extern __shared__ float4 lds[];
+    uint32_t* cand = reinterpret_cast<uint32_t*>(lds);              // [kCandSlots][kBlock]
+    float4* s_sph = lds + (kCandSlots * kBlock) / 4;
+    float4* s_tri = s_sph + A.sph_tile;
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+
+    if (!MULTI_TILE) {                                              // whole scene fits: stage once
+        for (uint32_t k = tid; k < A.n_sph; k += kBlock) s_sph[k] = A.sph[k];
+        for (uint32_t k = tid; k < A.n_tri * 4; k += kBlock) s_tri[k] = A.tri[k];
+        __syncthreads();
+    }
+
+    Path P;
+    P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
+    P.tr = P.tg = P.tb = 0.0f; P.lr = P.lg = P.lb = 0.0f; P.slot = 0; P.base = 0; P.depth = 0;
+    bool alive = false;
+    uint32_t chunk_next = 0, chunk_end = 0;                         // wave-uniform
+    bool exhausted = false;                                         // wave-uniform
+    unsigned long long casts = 0;                                   // wave-uniform
+
+    for (;;) {
+        // ---- refill: lanes whose path ended take the next samples of the wave's chunk (ballot + prefix count)
+        const unsigned long long need = __ballot(!alive);
+        if (need != 0ull && !exhausted) {
+            const uint32_t n_need = (uint32_t)__popcll(need);
+            const uint32_t rank = prefix_count(need);
+            uint32_t item = 0xFFFFFFFFu, taken = 0;
+            while (taken < n_need) {
+                if (chunk_next == chunk_end) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(A.work_counter, kWorkChunk);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    if (b >= A.total) { exhausted = true; break; }
+                    chunk_next = b;
+                    chunk_end = min(b + kWorkChunk, A.total);
+                }
+                const uint32_t k = min(n_need - taken, chunk_end - chunk_next);
+                if (!alive && rank >= taken && rank < taken + k) item = chunk_next + (rank - taken);
+                chunk_next += k;
+                taken += k;
+            }
+            if (item != 0xFFFFFFFFu) { start_path(A, item, P); alive = true; }
+        }
+        if (MULTI_TILE) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
+        else            { if (__ballot(alive) == 0ull) break; }
+        casts += (unsigned long long)__popcll(__ballot(alive));
+
+        // ---- nearest hit.  kind: 0 none, 1 triangle, 2 sphere; strict '<' keeps the earlier primitive.
+        float tbest = __builtin_inff();
+        uint32_t ibest = 0, kind = 0;
+        const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+
+        for (uint32_t t0 = 0; t0 < A.n_tri; t0 += A.tri_tile) {     // hit_vertex, raytracer_v4.glsl:116-153
+            const uint32_t cnt = min(A.tri_tile, A.n_tri - t0);
+            if (MULTI_TILE) {
+                __syncthreads();
+                for (uint32_t k = tid; k < cnt * 4; k += kBlock) s_tri[k] = A.tri[(size_t)t0 * 4 + k];
+                __syncthreads();
+            }
+            if (alive) {
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const float4 n = s_tri[4 * j];
+                    const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
+                    if (nd == 0.0f) continue;
+                    const float t = (n.w - dot3(n.x, n.y, n.z, ox, oy, oz)) / nd;
+                    if (!(t >= A.t_min && t < tbest)) continue;
+                    const float4 p1 = s_tri[4 * j + 1], p2 = s_tri[4 * j + 2], p3 = s_tri[4 * j + 3];
+                    const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+                    float ex, ey, ez, qx, qy, qz, cx, cy, cz;
+                    ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
+                    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+                    ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
+                    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+                    ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
+                    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+                    tbest = t; ibest = t0 + j; kind = 1;
+                }
+            }
+        }
+
+        for (uint32_t t0 = 0; t0 < A.n_sph; t0 += A.sph_tile) {     // hit_sphere, raytracer_v4.glsl:157-178, unit d
+            const uint32_t cnt = min(A.sph_tile, A.n_sph - t0);
+            if (MULTI_TILE) {
+                __syncthreads();
+                for (uint32_t k = tid; k < cnt; k += kBlock) s_sph[k] = A.sph[t0 + k];
+                __syncthreads();
+            }
+            if (alive) {
+                uint32_t ncand = 0;
+                // exact roots only for the few spheres whose line the ray can reach: candidates are queued in LDS
+                // and evaluated afterwards by all lanes together, keeping the hot loop free of divergent sqrt work.
+                auto flush = [&]() {
+                    for (uint32_t q = 0; q < ncand; q++) {
+                        const uint32_t j = cand[q * kBlock + tid];
+                        const float4 s = s_sph[j];
+                        const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+                        const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+                        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+                        const float sq = __builtin_sqrtf(fma_(h, h, -c));
+                        float t = h - sq;
+                        if (!(t > A.t_min)) t = h + sq;
+                        if (t > A.t_min && t < tbest) { tbest = t; ibest = t0 + j; kind = 2; }
+                    }
+                    ncand = 0;
+                };
+#pragma unroll 4
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const float4 s = s_sph[j];                      // wave-uniform address: LDS broadcast
+                    const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+                    const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+                    const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+                    const float disc = fma_(h, h, -c);
+                    if ((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f))) {
+                        if (ncand == kCandSlots) flush();
+                        cand[ncand * kBlock + tid] = j;
+                        ncand++;
+                    }
+                }
+                flush();
+            }
+        }
+
+        // ---- shade / scatter (book materials)
+        if (alive) {
+            bool done = false;
+            if (kind == 0) {
+                if (!(A.flags & RT3_FLAG_BLACK_BACKGROUND)) {
+                    float r, g, b;
+                    sky(dx, dy, dz, r, g, b);
+                    P.lr = fma_(P.tr, r, P.lr); P.lg = fma_(P.tg, g, P.lg); P.lb = fma_(P.tb, b, P.lb);
+                }
+                done = true;
+            } else {
+                float4 m; uint32_t mk;
+                float px, py, pz, nx, ny, nz;
+                if (kind == 1) {
+                    m = A.tri_mat[ibest]; mk = A.tri_kind[ibest];
+                    const float4 n = A.tri[(size_t)ibest * 4];
+                    px = ox + tbest * dx; py = oy + tbest * dy; pz = oz + tbest * dz;
+                    nx = n.x; ny = n.y; nz = n.z;
+                } else {
+                    m = A.sph_mat[ibest]; mk = A.sph_kind[ibest];
+                    const float4 s = A.sph[ibest];
+                    const float invr = A.sph_invr[ibest];
+                    px = fma_(tbest, dx, ox); py = fma_(tbest, dy, oy); pz = fma_(tbest, dz, oz);
+                    nx = (px - s.x) * invr; ny = (py - s.y) * invr; nz = (pz - s.z) * invr;
+                }
+                if (mk == RT3_MAT_FLAT) {
+                    P.lr = fma_(P.tr, m.x, P.lr); P.lg = fma_(P.tg, m.y, P.lg); P.lb = fma_(P.tb, m.z, P.lb);
+                    done = true;
+                } else if (P.depth + 1 == A.max_depth) {
+                    done = true;
+                } else {
+                    const bool front = dotf(dx, dy, dz, nx, ny, nz) < 0.0f;
+                    if (!front) { nx = -nx; ny = -ny; nz = -nz; }
+                    const uint32_t ctr = 1u + 8u * (P.depth + 1u);
+                    float sx, sy, sz;                               // scattered direction before normalisation
+                    float ar = m.x, ag = m.y, ab = m.z;
+                    if (mk == RT3_MAT_LAMBERT) {
+                        float vx, vy, vz;
+                        unit_vector(rnd(P.base, ctr), rnd(P.base, ctr + 1), vx, vy, vz);
+                        sx = nx + vx; sy = ny + vy; sz = nz + vz;
+                        if (__builtin_fabsf(sx) < 1e-8f && __builtin_fabsf(sy) < 1e-8f && __builtin_fabsf(sz) < 1e-8f) { sx = nx; sy = ny; sz = nz; }
+                    } else if (mk == RT3_MAT_METAL) {
+                        const float k2 = 2.0f * dotf(dx, dy, dz, nx, ny, nz);
+                        float rx = fma_(-k2, nx, dx), ry = fma_(-k2, ny, dy), rz = fma_(-k2, nz, dz);
+                        const float inv = 1.0f / __builtin_sqrtf(dotf(rx, ry, rz, rx, ry, rz));
+                        rx *= inv; ry *= inv; rz *= inv;
+                        sx = rx; sy = ry; sz = rz;
+                        if (m.w > 0.0f) {
+                            float vx, vy, vz;
+                            unit_vector(rnd(P.base, ctr), rnd(P.base, ctr + 1), vx, vy, vz);
+                            sx = fma_(m.w, vx, rx); sy = fma_(m.w, vy, ry); sz = fma_(m.w, vz, rz);
+                        }
+                        if (!(dotf(sx, sy, sz, nx, ny, nz) > 0.0f)) done = true;       // absorbed
+                    } else {                                        // dielectric
+                        const float ri = front ? 1.0f / m.w : m.w;
+                        float cosv = -dotf(dx, dy, dz, nx, ny, nz);
+                        if (cosv > 1.0f) cosv = 1.0f;
+                        const float s2 = fma_(-cosv, cosv, 1.0f);
+                        const float sinv = __builtin_sqrtf(s2 > 0.0f ? s2 : 0.0f);
+                        const bool cannot = ri * sinv > 1.0f;
+                        float r0 = (1.0f - ri) / (1.0f + ri);
+                        r0 = r0 * r0;
+                        const float xx = 1.0f - cosv, x2 = xx * xx, x5 = x2 * x2 * xx;
+                        const float R = fma_(1.0f - r0, x5, r0);
+                        if (cannot || R > rnd(P.base, ctr + 2)) {
+                            const float k2 = 2.0f * dotf(dx, dy, dz, nx, ny, nz);
+                            sx = fma_(-k2, nx, dx); sy = fma_(-k2, ny, dy); sz = fma_(-k2, nz, dz);
+                        } else {
+                            const float ex = fma_(cosv, nx, dx) * ri, ey = fma_(cosv, ny, dy) * ri, ez = fma_(cosv, nz, dz) * ri;
+                            const float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dotf(ex, ey, ez, ex, ey, ez)));
+                            sx = fma_(par, nx, ex); sy = fma_(par, ny, ey); sz = fma_(par, nz, ez);
+                        }
+                        ar = ag = ab = 1.0f;
+                    }
+                    if (!done) {
+                        const float inv = 1.0f / __builtin_sqrtf(dotf(sx, sy, sz, sx, sy, sz));
+                        P.dx = sx * inv; P.dy = sy * inv; P.dz = sz * inv;
+                        P.ox = px; P.oy = py; P.oz = pz;
+                        P.tr *= ar; P.tg *= ag; P.tb *= ab;
+                        P.depth += 1;
+                    }
+                }
+            }
+            if (done) {
+                A.rad[P.slot] = make_float4(P.lr, P.lg, P.lb, 0.0f);
+                alive = false;
+            }
+        }
+    }
+    if (lane == 0 && casts != 0) atomicAdd(A.cast_counter, casts);
+}
+
+// reduce pass (what reduce_v1.glsl:66-76 was meant to be): samples are summed per pixel in sample order.
+__global__ __launch_bounds__(kBlock) void k_accumulate(const float4* __restrict__ rad, float4* __restrict__ accum,
+                                                      uint32_t npix, uint32_t ns, int first) {
+    const uint32_t pix = blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= npix) return;
+    float4 a = first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : accum[pix];
+    for (uint32_t s = 0; s < ns; s++) {
+        const float4 r = rad[(size_t)s * npix + pix];
+        a.x = a.x + r.x; a.y = a.y + r.y; a.z = a.z + r.z;
+    }
+    accum[pix] = a;
+}
+__global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ accum, uint32_t npix, uint32_t spp,
+                                                   uint32_t flags, uint32_t* __restrict__ out) {
+    const uint32_t pix = blockIdx.x * kBlock + threadIdx.x;
+    if (pix >= npix) return;
+    const float4 a = accum[pix];
+    const float n = (float)spp;
+    float r = a.x / n, g = a.y / n, b = a.z / n;
+    if (flags & RT3_FLAG_GAMMA2) {
+        r = r > 0.0f ? __builtin_sqrtf(r) : 0.0f;
+        g = g > 0.0f ? __builtin_sqrtf(g) : 0.0f;
+        b = b > 0.0f ? __builtin_sqrtf(b) : 0.0f;
+    }
+    out[pix] = pack_pixel(r, g, b);
+}
+
+// device arithmetic probes for tests/test_gpu_arith.py
+__global__ void k_debug_arith(const float* a, const float* b, uint32_t n, float* div, float* sq, float* fm,
+                              float* cs, float* sn, float* sk, uint32_t* pk) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    div[i] = a[i] / b[i];
+    sq[i] = __builtin_sqrtf(__builtin_fabsf(a[i]));
+    fm[i] = fma_(a[i], b[i], a[i]);
+    const float u = u01(__float_as_uint(a[i]));
+    sincos2pi(u, cs[i], sn[i]);
+    float r, g, bl;
+    sky(a[i], b[i], -2.0f, r, g, bl);
+    sk[3 * i] = r; sk[3 * i + 1] = g; sk[3 * i + 2] = bl;
+    pk[i] = pack_pixel(a[i], b[i], u);
+}
+
+}  // namespace
+
+// ======================================================================================================
+// Host side of the device context
+// ======================================================================================================
+struct rt3_ctx {
+    int device = 0;
+    int num_cu = 0;
+    hipStream_t stream = nullptr;                                   // used by the synchronous entry points
+    std::string err;
+
+    // mesh
+    uint32_t n_faces = 0;
+    float4* d_tri = nullptr; float4* d_tri_mat = nullptr; uint32_t* d_tri_kind = nullptr;
+    // spheres
+    uint32_t n_sph = 0;
+    float4* d_sph = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
+
+    // work buffers
+    float4* d_rad = nullptr; size_t rad_entries = 0;
+    float4* d_accum = nullptr; size_t accum_entries = 0;
+    uint32_t* d_out = nullptr; size_t out_entries = 0;
+    uint32_t* d_work = nullptr;                                     // [0] work counter
+    unsigned long long* d_casts = nullptr;
+    uint64_t rad_cap_bytes = 16ull << 30;
+
+    // stats of the last render
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;              // per dominant-kernel launch
+    uint32_t ev_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipStream_t last_stream = nullptr;
+    uint64_t last_samples = 0;
+    bool last_was_path = false;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define RT3_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+            return RT3_E_DEVICE;                                                                        \
+        }                                                                                               \
+    } while (0)
+
+int fail(rt3_ctx* ctx, int code, const std::string& msg) { ctx->err = msg; return code; }
+
+template <typename T>
+int upload(rt3_ctx* ctx, T** dst, const std::vector<T>& src) {
+    if (*dst) { RT3_HIP(hipFree(*dst)); *dst = nullptr; }
+    if (src.empty()) return 0;
+    RT3_HIP(hipMalloc((void**)dst, src.size() * sizeof(T)));
+    RT3_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+template <typename T>
+int ensure(rt3_ctx* ctx, T** buf, size_t* have, size_t want) {
+    if (*have >= want && *buf) return 0;
+    if (*buf) { RT3_HIP(hipFree(*buf)); *buf = nullptr; *have = 0; }
+    RT3_HIP(hipMalloc((void**)buf, want * sizeof(T)));
+    *have = want;
+    return 0;
+}
+
+CamDev cam_dev(const rt3_camera* c) {
+    return CamDev{ c->origin[0], c->origin[1], c->origin[2], c->horizontal[0], c->horizontal[1], c->horizontal[2],
+                   c->vertical[0], c->vertical[1], c->vertical[2],
+                   c->lower_left_corner[0], c->lower_left_corner[1], c->lower_left_corner[2] };
+}
+
+int take_event_pair(rt3_ctx* ctx, hipEvent_t* a, hipEvent_t* b) {
+    if (ctx->ev_used == ctx->ev.size()) {
+        hipEvent_t x, y;
+        RT3_HIP(hipEventCreate(&x));
+        RT3_HIP(hipEventCreate(&y));
+        ctx->ev.emplace_back(x, y);
+    }
+    *a = ctx->ev[ctx->ev_used].first;
+    *b = ctx->ev[ctx->ev_used].second;
+    ctx->ev_used++;
+    return 0;
+}
+
+bool row_owned(const rt3_params* p, uint32_t y) {
+    if (p->tile_count <= 1) return true;
+    return ((y / p->tile_rows) % p->tile_count) == p->tile_index;
+}
+
+int check_params(rt3_ctx* ctx, const rt3_params* p) {
+    if (!p) return fail(ctx, RT3_E_ARG, "params is NULL");
+    if (p->width < 2 || p->height < 2) return fail(ctx, RT3_E_ARG, "width and height must be >= 2");
+    if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(ctx, RT3_E_ARG, "frame too large");
+    if (p->spp < 1 || p->max_depth < 1) return fail(ctx, RT3_E_ARG, "spp and max_depth must be >= 1");
+    if (p->tile_count > 1 && (p->tile_rows == 0 || p->tile_index >= p->tile_count))
+        return fail(ctx, RT3_E_ARG, "bad tile_rows / tile_index / tile_count");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt3_rows_owned(const rt3_params* p) {
+    uint32_t n = 0;
+    for (uint32_t y = 0; y < p->height; y++) n += row_owned(p, y) ? 1u : 0u;
+    return n;
+}
+uint32_t rt3_row_of_local(const rt3_params* p, uint32_t local_row) {
+    if (p->tile_count <= 1) return local_row;
+    const uint32_t lb = local_row / p->tile_rows, in = local_row % p->tile_rows;
+    return (lb * p->tile_count + p->tile_index) * p->tile_rows + in;
+}
+
+rt3_ctx* rt3_create(int device_id) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("rt3_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                         "); this library has no CPU fallback";
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= count) { g_create_error = "rt3_create: device_id out of range"; return nullptr; }
+    rt3_ctx* ctx = new rt3_ctx();
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreate(&ctx->stream)) != hipSuccess || (e = hipEventCreate(&ctx->ev_begin)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_end)) != hipSuccess ||
+        (e = hipMalloc((void**)&ctx->d_work, 64)) != hipSuccess || (e = hipMalloc((void**)&ctx->d_casts, 64)) != hipSuccess) {
+        g_create_error = std::string("rt3_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return nullptr;
+    }
+    ctx->num_cu = prop.multiProcessorCount;
+    return ctx;
+}
+
+void rt3_destroy(rt3_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    void* bufs[] = { ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_sph, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
+                     ctx->d_rad, ctx->d_accum, ctx->d_out, ctx->d_work, ctx->d_casts };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rt3_last_error(const rt3_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt3_set_sample_storage_cap(rt3_ctx* ctx, uint64_t bytes) {
+    if (!ctx) return RT3_E_ARG;
+    if (bytes < (1ull << 20)) return fail(ctx, RT3_E_ARG, "sample storage cap must be >= 1 MiB");
+    ctx->rad_cap_bytes = bytes;
+    return 0;
+}
+
+int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const float* vertices, uint32_t n_vertices,
+                 const rt3_material* face_materials) {
+    if (!ctx) return RT3_E_ARG;
+    if (n_faces != 0 && (!faces || !vertices)) return fail(ctx, RT3_E_ARG, "faces / vertices is NULL");
+    RT3_HIP(hipSetDevice(ctx->device));
+    // de-index into 4 x float4 per face, in face order (order defines tie-breaking: SequentialRenderer.cpp:71)
+    std::vector<float4> tri((size_t)n_faces * 4), mat(n_faces);
+    std::vector<uint32_t> kind(n_faces);
+    for (uint32_t i = 0; i < n_faces; i++) {
+        const rt3_gface& f = faces[i];
+        if (f.v1 >= n_vertices || f.v2 >= n_vertices || f.v3 >= n_vertices)
+            return fail(ctx, RT3_E_ARG, "face " + std::to_string(i) + " references a vertex out of range");
+        const float* p1 = vertices + 4 * (size_t)f.v1;
+        const float* p2 = vertices + 4 * (size_t)f.v2;
+        const float* p3 = vertices + 4 * (size_t)f.v3;
+        const float pd = f.normal[0] * p1[0] + f.normal[1] * p1[1] + f.normal[2] * p1[2];     // dot3(normal, p1), :67
+        tri[4 * (size_t)i] = make_float4(f.normal[0], f.normal[1], f.normal[2], pd);
+        tri[4 * (size_t)i + 1] = make_float4(p1[0], p1[1], p1[2], 0.0f);
+        tri[4 * (size_t)i + 2] = make_float4(p2[0], p2[1], p2[2], 0.0f);
+        tri[4 * (size_t)i + 3] = make_float4(p3[0], p3[1], p3[2], 0.0f);
+        if (face_materials) {
+            const rt3_material& m = face_materials[i];
+            if (m.kind > RT3_MAT_DIELECTRIC) return fail(ctx, RT3_E_ARG, "unknown material kind");
+            mat[i] = make_float4(m.rgb[0], m.rgb[1], m.rgb[2], m.param);
+            kind[i] = m.kind;
+        } else {
+            mat[i] = make_float4(f.color[0], f.color[1], f.color[2], 0.0f);
+            kind[i] = RT3_MAT_FLAT;
+        }
+    }
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_tri, tri)) || (rc = upload(ctx, &ctx->d_tri_mat, mat)) || (rc = upload(ctx, &ctx->d_tri_kind, kind)))
+        return rc;
+    ctx->n_faces = n_faces;
+    return 0;
+}
+
+int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material* materials, uint32_t n) {
+    if (!ctx) return RT3_E_ARG;
+    if (n != 0 && (!center_radius || !materials)) return fail(ctx, RT3_E_ARG, "center_radius / materials is NULL");
+    RT3_HIP(hipSetDevice(ctx->device));
+    std::vector<float4> sph(n), mat(n);
+    std::vector<float> invr(n);
+    std::vector<uint32_t> kind(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float* s = center_radius + 4 * (size_t)i;
+        if (!(s[3] > 0.0f)) return fail(ctx, RT3_E_ARG, "sphere " + std::to_string(i) + " has a non-positive radius");
+        if (materials[i].kind > RT3_MAT_DIELECTRIC) return fail(ctx, RT3_E_ARG, "unknown material kind");
+        sph[i] = make_float4(s[0], s[1], s[2], s[3] * s[3]);
+        invr[i] = 1.0f / s[3];
+        mat[i] = make_float4(materials[i].rgb[0], materials[i].rgb[1], materials[i].rgb[2], materials[i].param);
+        kind[i] = materials[i].kind;
+    }
+    int rc;
+    if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
+        (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
+        return rc;
+    ctx->n_sph = n;
+    return 0;
+}
+
+int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint32_t height, void* d_out, void* stream_) {
+    if (!ctx) return RT3_E_ARG;
+    if (!cam || !d_out) return fail(ctx, RT3_E_ARG, "cam / d_out_pixels is NULL");
+    if (width < 2 || height < 2 || (uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RT3_E_ARG, "bad frame size");
+    RT3_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    ctx->ev_used = 0;
+    hipEvent_t a, b;
+    int rc = take_event_pair(ctx, &a, &b);
+    if (rc) return rc;
+    const uint32_t npix = width * height;
+    RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
+    RT3_HIP(hipEventRecord(a, stream));
+    hipLaunchKernelGGL(k_mode_r, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       ctx->d_tri, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
+    RT3_HIP(hipGetLastError());
+    RT3_HIP(hipEventRecord(b, stream));
+    RT3_HIP(hipEventRecord(ctx->ev_end, stream));
+    ctx->last_stream = stream;
+    ctx->last_samples = npix;
+    ctx->last_was_path = false;
+    return 0;
+}
+
+int rt3_render(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint32_t height, uint32_t* out_pixels) {
+    if (!ctx) return RT3_E_ARG;
+    if (!out_pixels) return fail(ctx, RT3_E_ARG, "out_pixels is NULL");
+    if (width < 2 || height < 2 || (uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RT3_E_ARG, "bad frame size");
+    RT3_HIP(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)width * height;
+    int rc = ensure(ctx, &ctx->d_out, &ctx->out_entries, npix);
+    if (rc) return rc;
+    if ((rc = rt3_render_device(ctx, cam, width, height, ctx->d_out, ctx->stream))) return rc;
+    RT3_HIP(hipMemcpyAsync(out_pixels, ctx->d_out, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, void* d_out, void* stream_) {
+    if (!ctx) return RT3_E_ARG;
+    if (!cam || !d_out) return fail(ctx, RT3_E_ARG, "cam / d_out_pixels is NULL");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (ctx->n_sph == 0 && ctx->n_faces == 0) return fail(ctx, RT3_E_STATE, "no scene: call rt3_set_spheres / rt3_set_mesh first");
+    RT3_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_;
+
+    const uint32_t rows = rt3_rows_owned(p);
+    const uint32_t npix = rows * p->width;
+    ctx->ev_used = 0;
+    ctx->last_stream = stream;
+    ctx->last_samples = (uint64_t)npix * p->spp;
+    ctx->last_was_path = true;
+    RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
+    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 8, stream));
+    if (npix == 0) { RT3_HIP(hipEventRecord(ctx->ev_end, stream)); return 0; }
+
+    // batch size: per-sample storage of 16 B per (pixel, sample), capped
+    uint64_t per_spp = (uint64_t)npix * sizeof(float4);
+    uint32_t batch = (uint32_t)std::min<uint64_t>(p->spp, std::max<uint64_t>(1, ctx->rad_cap_bytes / per_spp));
+    batch = (uint32_t)std::min<uint64_t>(batch, 0x7FFF0000ull / npix);
+    if (batch == 0) return fail(ctx, RT3_E_ARG, "frame too large for one sample batch");
+    if ((rc = ensure(ctx, &ctx->d_rad, &ctx->rad_entries, (size_t)npix * batch))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_accum, &ctx->accum_entries, (size_t)npix))) return rc;
+
+    TraceArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.sph = ctx->d_sph; A.sph_invr = ctx->d_sph_invr; A.sph_mat = ctx->d_sph_mat; A.sph_kind = ctx->d_sph_kind; A.n_sph = ctx->n_sph;
+    A.tri = ctx->d_tri; A.tri_mat = ctx->d_tri_mat; A.tri_kind = ctx->d_tri_kind; A.n_tri = ctx->n_faces;
+    const bool multi = ctx->n_sph > kSphTileMax || ctx->n_faces > kTriTileMax;
+    A.sph_tile = std::max(1u, std::min(ctx->n_sph, kSphTileMax));
+    A.tri_tile = std::max(1u, std::min(ctx->n_faces, kTriTileMax));
+    A.cam = cam_dev(cam);
+    A.lens_radius = p->lens_radius;
+    {
+        const float* h = cam->horizontal; const float* v = cam->vertical;
+        const float lh = std::sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+        const float lv = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        A.lux = h[0] / lh; A.luy = h[1] / lh; A.luz = h[2] / lh;
+        A.lvx = v[0] / lv; A.lvy = v[1] / lv; A.lvz = v[2] / lv;
+    }
+    A.width = p->width; A.height = p->height; A.spp = p->spp; A.max_depth = p->max_depth; A.seed = p->seed; A.flags = p->flags;
+    {
+        uint32_t e = (uint32_t)std::sqrt((double)p->spp);
+        while (e * e > p->spp) e--;
+        while ((e + 1) * (e + 1) <= p->spp) e++;
+        A.edge = (e * e == p->spp && p->spp > 1) ? e : 0;          // stratified only for perfect squares (v4:199)
+    }
+    A.t_min = p->t_min;
+    A.tile_rows = p->tile_rows; A.tile_index = p->tile_index; A.tile_count = p->tile_count;
+    A.npix = npix;
+    A.rad = ctx->d_rad; A.work_counter = ctx->d_work; A.cast_counter = ctx->d_casts;
+
+    const size_t lds_bytes = (size_t)kCandSlots * kBlock * 4 + (size_t)A.sph_tile * 16 + (size_t)(ctx->n_faces ? A.tri_tile : 0) * 64;
+    int per_cu = 0;
+    if (multi) RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<true>, kBlock, lds_bytes));
+    else       RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kBlock, lds_bytes));
+    if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_trace does not fit on a CU");
+    per_cu = std::min(per_cu, 8);
+
+    for (uint32_t s0 = 0; s0 < p->spp; s0 += batch) {
+        const uint32_t ns = std::min(batch, p->spp - s0);
+        A.s0 = s0;
+        A.total = npix * ns;
+        const uint32_t want_blocks = (A.total + kWorkChunk * 4 - 1) / (kWorkChunk * 4);
+        const uint32_t grid = std::max(1u, std::min<uint32_t>((uint32_t)(ctx->num_cu * per_cu), want_blocks));
+        hipEvent_t a, b;
+        if ((rc = take_event_pair(ctx, &a, &b))) return rc;
+        RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
+        RT3_HIP(hipEventRecord(a, stream));
+        if (multi) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
+        else       hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
+        RT3_HIP(hipGetLastError());
+        RT3_HIP(hipEventRecord(b, stream));
+        hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                           ctx->d_rad, ctx->d_accum, npix, ns, s0 == 0 ? 1 : 0);
+        RT3_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_resolve, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                       ctx->d_accum, npix, p->spp, p->flags, (uint32_t*)d_out);
+    RT3_HIP(hipGetLastError());
+    RT3_HIP(hipEventRecord(ctx->ev_end, stream));
+    return 0;
+}
+
+int rt3_render_path(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, uint32_t* out_pixels) {
+    if (!ctx) return RT3_E_ARG;
+    if (!out_pixels) return fail(ctx, RT3_E_ARG, "out_pixels is NULL");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    RT3_HIP(hipSetDevice(ctx->device));
+    const size_t npix = (size_t)rt3_rows_owned(p) * p->width;
+    if ((rc = ensure(ctx, &ctx->d_out, &ctx->out_entries, std::max<size_t>(npix, 1)))) return rc;
+    if ((rc = rt3_render_path_device(ctx, cam, p, ctx->d_out, ctx->stream))) return rc;
+    if (npix) RT3_HIP(hipMemcpyAsync(out_pixels, ctx->d_out, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
+    if (!ctx || !out) return RT3_E_ARG;
+    RT3_HIP(hipSetDevice(ctx->device));
+    std::memset(out, 0, sizeof *out);
+    if (ctx->ev_used == 0) return fail(ctx, RT3_E_STATE, "no render has been issued on this context");
+    RT3_HIP(hipEventSynchronize(ctx->ev_end));
+    float ms = 0.0f;
+    for (uint32_t i = 0; i < ctx->ev_used; i++) {
+        float t = 0.0f;
+        RT3_HIP(hipEventElapsedTime(&t, ctx->ev[i].first, ctx->ev[i].second));
+        ms += t;
+    }
+    out->trace_ms = ms;
+    RT3_HIP(hipEventElapsedTime(&out->total_ms, ctx->ev_begin, ctx->ev_end));
+    out->launches = ctx->ev_used;
+    out->samples = ctx->last_samples;
+    out->n_spheres = ctx->n_sph;
+    out->n_faces = ctx->n_faces;
+    if (ctx->last_was_path) {
+        unsigned long long casts = 0;
+        RT3_HIP(hipMemcpy(&casts, ctx->d_casts, 8, hipMemcpyDeviceToHost));
+        out->ray_casts = casts;
+        out->prim_tests = casts * ((uint64_t)ctx->n_sph + ctx->n_faces);
+    } else {
+        out->ray_casts = ctx->last_samples;
+        out->prim_tests = ctx->last_samples * (uint64_t)ctx->n_faces;
+    }
+    return 0;
+}
+
+// Debug probe (tests only): element-wise device arithmetic, see tests/test_gpu_arith.py.
+int rt3_debug_arith(rt3_ctx* ctx, const float* a, const float* b, uint32_t n, float* div, float* sq, float* fm,
+                    float* cs, float* sn, float* sk3, uint32_t* pk) {
+    if (!ctx) return RT3_E_ARG;
+    RT3_HIP(hipSetDevice(ctx->device));
+    float* d = nullptr;
+    const size_t N = n;
+    RT3_HIP(hipMalloc((void**)&d, N * 4 * 11));
+    float *da = d, *db = d + N, *ddiv = d + 2 * N, *dsq = d + 3 * N, *dfm = d + 4 * N, *dcs = d + 5 * N, *dsn = d + 6 * N, *dsk = d + 7 * N;
+    uint32_t* dpk = (uint32_t*)(d + 10 * N);
+    RT3_HIP(hipMemcpy(da, a, N * 4, hipMemcpyHostToDevice));
+    RT3_HIP(hipMemcpy(db, b, N * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_arith, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, da, db, n, ddiv, dsq, dfm, dcs, dsn, dsk, dpk);
+    RT3_HIP(hipGetLastError());
+    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    RT3_HIP(hipMemcpy(div, ddiv, N * 4, hipMemcpyDeviceToHost));
+    RT3_HIP(hipMemcpy(sq, dsq, N * 4, hipMemcpyDeviceToHost));
+    RT3_HIP(hipMemcpy(fm, dfm, N * 4, hipMemcpyDeviceToHost));
+    RT3_HIP(hipMemcpy(cs, dcs, N * 4, hipMemcpyDeviceToHost));
+    RT3_HIP(hipMemcpy(sn, dsn, N * 4, hipMemcpyDeviceToHost));
+    RT3_HIP(hipMemcpy(sk3, dsk, N * 12, hipMemcpyDeviceToHost));
+    RT3_HIP(hipMemcpy(pk, dpk, N * 4, hipMemcpyDeviceToHost));
+    RT3_HIP(hipFree(d));
+    return 0;
+}
+
+}  // extern "C"

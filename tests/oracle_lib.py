@@ -1,0 +1,182 @@
+"""ctypes binding of oracle/librt3oracle.so — the CPU restatement used as the parity checker.
+
+Test infrastructure only: nothing under raytracer-3_amd/ imports this module.
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "librt3oracle.so")
+
+GFACE = np.dtype([("v1", "<u4"), ("v2", "<u4"), ("v3", "<u4"), ("_p0", "<u4"),
+                  ("normal", "<f4", 3), ("_p1", "<u4"), ("color", "<f4", 3), ("_p2", "<u4")])
+MATERIAL = np.dtype([("rgb", "<f4", 3), ("param", "<f4"), ("kind", "<u4")])
+assert GFACE.itemsize == 48 and MATERIAL.itemsize == 20
+
+MAT_FLAT, MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
+FLAG_GAMMA2, FLAG_BLACK = 1, 2
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("lower_left_corner", C.c_float * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_uint32),
+                ("seed", C.c_uint32), ("flags", C.c_uint32), ("lens_radius", C.c_float), ("t_min", C.c_float),
+                ("tile_rows", C.c_uint32), ("tile_index", C.c_uint32), ("tile_count", C.c_uint32)]
+
+
+def make_params(width, height, spp=1, max_depth=1, seed=1, flags=0, lens_radius=0.0, t_min=0.001,
+                tile_rows=8, tile_index=0, tile_count=1):
+    return Params(width, height, spp, max_depth, seed, flags, lens_radius, t_min, tile_rows, tile_index, tile_count)
+
+
+def build_oracle():
+    src = os.path.join(ORACLE_DIR, "rt3_oracle.c")
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return ORACLE_SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_oracle())
+        _lib.oracle_sphere_face_count.restype = C.c_uint32
+        _lib.oracle_sphere_vertex_count.restype = C.c_uint32
+        _lib.oracle_hash_u32.restype = C.c_uint32
+        _lib.oracle_hash_u32.argtypes = [C.c_uint32]
+        _lib.oracle_random_float.restype = C.c_float
+        _lib.oracle_random_float.argtypes = [C.c_uint32]
+        _lib.oracle_frame_ppm_bytes.restype = C.c_uint64
+        _lib.oracle_render_path.restype = C.c_uint64
+        _lib.oracle_rows_owned.restype = C.c_uint32
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def prerender_triangle(p1, p2, p3, color):
+    faces = np.zeros(1, GFACE)
+    verts = np.zeros((3, 4), np.float32)
+    lib().oracle_prerender_triangle(_f3(p1), _f3(p2), _f3(p3), _f3(color), _p(faces), _p(verts))
+    return faces, verts
+
+
+def prerender_sphere(center, radius, m, p, color):
+    nf = lib().oracle_sphere_face_count(C.c_uint32(m), C.c_uint32(p))
+    nv = lib().oracle_sphere_vertex_count(C.c_uint32(m), C.c_uint32(p))
+    faces = np.zeros(nf, GFACE)
+    verts = np.zeros((nv, 4), np.float32)
+    lib().oracle_prerender_sphere(_f3(center), C.c_float(radius), C.c_uint32(m), C.c_uint32(p), _f3(color),
+                                  _p(faces), _p(verts))
+    return faces, verts
+
+
+def prerender_object(path, center, scale, color):
+    nf, nv = C.c_uint32(), C.c_uint32()
+    rc = lib().oracle_object_count(path.encode(), C.byref(nf), C.byref(nv))
+    if rc:
+        raise IOError("oracle_object_count(%s) = %d" % (path, rc))
+    faces = np.zeros(nf.value, GFACE)
+    verts = np.zeros((nv.value, 4), np.float32)
+    rc = lib().oracle_prerender_object(path.encode(), _f3(center), C.c_float(np.float32(scale)), _f3(color),
+                                       _p(faces), nf, _p(verts), nv)
+    if rc:
+        raise IOError("oracle_prerender_object(%s) = %d" % (path, rc))
+    return faces, verts
+
+
+def merge(entities):
+    """SequentialRenderer::prerender's merge: entities = [(faces, verts), ...] in order."""
+    nf = sum(len(f) for f, _ in entities)
+    nv = sum(len(v) for _, v in entities)
+    faces = np.zeros(nf, GFACE)
+    verts = np.zeros((nv, 4), np.float32)
+    cf, cv = C.c_uint32(0), C.c_uint32(0)
+    for f, v in entities:
+        f = np.ascontiguousarray(f)
+        v = np.ascontiguousarray(v, np.float32)
+        lib().oracle_transfer_entity(_p(faces), C.byref(cf), _p(verts), C.byref(cv), _p(f), C.c_uint32(len(f)),
+                                     _p(v), C.c_uint32(len(v)))
+    return faces, verts
+
+
+def camera_update(width, height, focal=2.0, vw=None, vh=2.0):
+    """Main.cpp:272: cam.update(W, H, 2.0, (float(W)/float(H))*2.0f, 2.0f)."""
+    if vw is None:
+        vw = np.float32(np.float32(width) / np.float32(height)) * np.float32(2.0)
+    cam = Camera()
+    lib().oracle_camera_update(C.byref(cam), C.c_float(focal), C.c_float(vw), C.c_float(vh))
+    return cam
+
+
+def render_mode_r(faces, verts, cam, w, h, y0=0, y1=None, threads=8, out=None):
+    if y1 is None:
+        y1 = h
+    if out is None:
+        out = np.zeros((h, w), np.uint32)
+    faces = np.ascontiguousarray(faces)
+    verts = np.ascontiguousarray(verts, np.float32)
+    lib().oracle_render_mode_r(_p(faces), C.c_uint32(len(faces)), _p(verts), C.c_uint32(len(verts)), C.byref(cam),
+                               C.c_uint32(w), C.c_uint32(h), C.c_uint32(y0), C.c_uint32(y1), _p(out), C.c_int(threads))
+    return out
+
+
+def render_path(cam, params, spheres=None, smats=None, faces=None, verts=None, fmats=None, threads=8, want_sum=False):
+    ns = 0 if spheres is None else len(spheres)
+    nf = 0 if faces is None else len(faces)
+    if spheres is not None:
+        spheres = np.ascontiguousarray(spheres, np.float32)
+        smats = np.ascontiguousarray(smats)
+        assert smats.dtype == MATERIAL and len(smats) == ns
+    if faces is not None:
+        faces = np.ascontiguousarray(faces)
+        verts = np.ascontiguousarray(verts, np.float32)
+        if fmats is not None:
+            fmats = np.ascontiguousarray(fmats)
+            assert fmats.dtype == MATERIAL and len(fmats) == nf
+    rows = lib().oracle_rows_owned(C.byref(params))
+    out = np.zeros((rows, params.width), np.uint32)
+    osum = np.zeros((rows, params.width, 3), np.float32) if want_sum else None
+    casts = lib().oracle_render_path(_p(faces), C.c_uint32(nf), _p(verts), _p(fmats), _p(spheres), _p(smats),
+                                     C.c_uint32(ns), C.byref(cam), C.byref(params), _p(out), _p(osum), C.c_int(threads))
+    if want_sum:
+        return out, osum, casts
+    return out, casts
+
+
+def ppm_bytes(pixels):
+    pixels = np.ascontiguousarray(pixels, np.uint32)
+    h, w = pixels.shape
+    need = lib().oracle_frame_ppm_bytes(_p(pixels), C.c_uint32(w), C.c_uint32(h), None, C.c_uint64(0))
+    buf = np.zeros(need, np.uint8)
+    got = lib().oracle_frame_ppm_bytes(_p(pixels), C.c_uint32(w), C.c_uint32(h), _p(buf), C.c_uint64(need))
+    assert got == need
+    return buf.tobytes()
+
+
+def sha256(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def sincos2pi(u):
+    c, s = C.c_float(), C.c_float()
+    lib().oracle_sincos2pi(C.c_float(u), C.byref(c), C.byref(s))
+    return c.value, s.value
