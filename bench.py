@@ -125,28 +125,14 @@ def main():
     params = [rt3.make_params(W, H, spp=args.spp, max_depth=args.depth, seed=RENDER_SEED, flags=rt3.FLAG_GAMMA2,
                               lens_radius=0.05, tile_rows=TILE_ROWS, tile_index=i, tile_count=world) for i in range(world)]
     my = params[rank]
-    rows = [rt3.rows_owned(p) for p in params]
-    max_rows = max(rows)
-    tile = torch.zeros((max_rows, W), dtype=torch.int32, device=dev)       # padded to the largest shard for the gather
-    frame = torch.zeros((H, W), dtype=torch.int32, device=dev) if rank == 0 else None
-    gather_list, row_index = None, None
-    if world > 1 and rank == 0:
-        gather_list = [torch.zeros_like(tile) for _ in range(world)]
-        idx = []
-        for i, p in enumerate(params):
-            idx.append(torch.tensor([rt3.row_of_local(p, k) for k in range(rows[i])], dtype=torch.long, device=dev))
-        row_index = idx
+    shard = importlib.import_module("raytracer-3_amd.shard")
+    g = shard.FrameGatherer(rt3, params, rank, dev)
+    tile = g.tile
     stream = torch.cuda.current_stream()
 
     def step():
         r.render_path_device(cam.c, my, tile.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.gather(tile, gather_list, dst=0)                        # RCCL over xGMI: 8.3 MB / world per peer
-            if rank == 0:
-                for i in range(world):
-                    frame.index_copy_(0, row_index[i], gather_list[i][: rows[i]])
-        elif rank == 0:
-            frame.copy_(tile[:H])
+        g.gather()                                                       # N>1: ONE RCCL gather over xGMI (8.3 MB / N per peer)
 
     def sync():
         if world > 1:
@@ -207,7 +193,7 @@ def main():
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         if args.save_ppm:
             f = rt3.Frame(W, H)
-            f.data[:] = frame.cpu().numpy().view(np.uint32)
+            f.data[:] = g.frame.cpu().numpy().view(np.uint32)
             f.to_ppm(args.save_ppm)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -531,3 +531,29 @@ uint64_t oracle_render_path(const rt3_gface* faces, uint32_t nf, const float* ve
 void oracle_arith(const float* a, const float* b, uint32_t n, float* div, float* sq, float* fm) {
     for (uint32_t i = 0; i < n; i++) { div[i] = a[i] / b[i]; sq[i] = sqrtf(fabsf(a[i])); fm[i] = fmaf(a[i], b[i], a[i]); }
 }
+
+/* ---- small probes for the known-answer tests (tests/test_oracle_kat.py) ---- */
+void oracle_sky(const float* d, float* rgb) { v3 c = sky(v3p(d)); rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z; }
+uint32_t oracle_pack_pixel(float r, float g, float b) { return pack_pixel(V(r, g, b)); }
+/* nearest hit of one ray; returns kind (0 none / 1 triangle / 2 sphere). */
+int oracle_nearest(const rt3_gface* faces, uint32_t nf, const float* verts, const float* spheres, uint32_t ns,
+                   const float* o, const float* d, float tmin, float* t, uint32_t* idx) {
+    scene_t sc = { faces, nf, verts, NULL, spheres, NULL, ns };
+    return nearest(&sc, v3p(o), v3p(d), tmin, t, idx);
+}
+/* Mode-R colour of one ray (ray_color, SequentialRenderer.cpp:47-109). */
+void oracle_ray_color(const rt3_gface* faces, uint32_t nf, const float* verts, const float* o, const float* d, float* rgb) {
+    v3 c = mode_r_ray_color(faces, nf, verts, v3p(o), v3p(d));
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+/* sky + pack applied element-wise, for the device arithmetic parity test. */
+void oracle_arith2(const float* a, const float* b, uint32_t n, float* cs, float* sn, float* sk3, uint32_t* pk) {
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t bits; memcpy(&bits, &a[i], 4);
+        float u = oracle_random_float(bits);
+        oracle_sincos2pi(u, &cs[i], &sn[i]);
+        v3 c = sky(V(a[i], b[i], -2.0f));
+        sk3[3 * i] = c.x; sk3[3 * i + 1] = c.y; sk3[3 * i + 2] = c.z;
+        pk[i] = pack_pixel(V(a[i], b[i], u));
+    }
+}

@@ -180,3 +180,58 @@ def sincos2pi(u):
     c, s = C.c_float(), C.c_float()
     lib().oracle_sincos2pi(C.c_float(u), C.byref(c), C.byref(s))
     return c.value, s.value
+
+
+def sky(d):
+    out = (C.c_float * 3)()
+    lib().oracle_sky(_f3(d), out)
+    return tuple(out)
+
+
+def pack_pixel(r, g, b):
+    lib().oracle_pack_pixel.restype = C.c_uint32
+    return lib().oracle_pack_pixel(C.c_float(r), C.c_float(g), C.c_float(b))
+
+
+def nearest(o, d, spheres=None, faces=None, verts=None, tmin=0.001):
+    """(kind, t, index) of the Mode-X nearest hit of one ray; kind 0 none / 1 triangle / 2 sphere."""
+    ns = 0 if spheres is None else len(spheres)
+    nf = 0 if faces is None else len(faces)
+    if spheres is not None:
+        spheres = np.ascontiguousarray(spheres, np.float32)
+    if faces is not None:
+        faces = np.ascontiguousarray(faces)
+        verts = np.ascontiguousarray(verts, np.float32)
+    t, i = C.c_float(), C.c_uint32()
+    kind = lib().oracle_nearest(_p(faces), C.c_uint32(nf), _p(verts), _p(spheres), C.c_uint32(ns), _f3(o), _f3(d),
+                                C.c_float(tmin), C.byref(t), C.byref(i))
+    return kind, t.value, i.value
+
+
+def ray_color(faces, verts, o, d):
+    faces = np.ascontiguousarray(faces)
+    verts = np.ascontiguousarray(verts, np.float32)
+    out = (C.c_float * 3)()
+    lib().oracle_ray_color(_p(faces), C.c_uint32(len(faces)), _p(verts), _f3(o), _f3(d), out)
+    return tuple(out)
+
+
+def arith(a, b):
+    """Host IEEE results for the device arithmetic parity test: div, sqrt, fma, cos/sin(2 pi u), sky, pack."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    n = len(a)
+    div, sq, fm, cs, sn = [np.zeros(n, np.float32) for _ in range(5)]
+    sk = np.zeros((n, 3), np.float32)
+    pk = np.zeros(n, np.uint32)
+    lib().oracle_arith(_p(a), _p(b), C.c_uint32(n), _p(div), _p(sq), _p(fm))
+    lib().oracle_arith2(_p(a), _p(b), C.c_uint32(n), _p(cs), _p(sn), _p(sk), _p(pk))
+    return div, sq, fm, cs, sn, sk, pk
+
+
+def copy_camera(c):
+    """rt3_camera (product) -> oracle Camera (same layout)."""
+    out = Camera()
+    for f in ("origin", "horizontal", "vertical", "lower_left_corner"):
+        setattr(out, f, getattr(c, f))
+    return out
