@@ -83,6 +83,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise Fatal("librt3hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
                     "there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 under the same SONAME.  If torch is going to
+    # be used in this process (device buffers, streams, RCCL) it has to be loaded first, or its later CUDA init fails
+    # with "No HIP GPUs are available"; librt3hip.so then binds to the runtime that is already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
     sigs = {
