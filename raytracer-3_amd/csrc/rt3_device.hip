@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rt3.h"
@@ -34,6 +35,9 @@ constexpr uint32_t kWorkChunk   = 256;     // samples a wave takes from the glob
 constexpr uint32_t kSphTileMax  = 1024;    // spheres per LDS tile (16 KiB)
 constexpr uint32_t kTriTileMax  = 256;     // faces per LDS tile (4 x float4 = 16 KiB)
 constexpr uint32_t kModeRTile   = 512;     // faces per LDS tile in k_mode_r (32 KiB)
+
+// filler for the tail of a sphere tile: r^2 = -1e30 makes the discriminant negative for every ray
+#define kPadSphere make_float4(0.0f, 0.0f, 0.0f, -1e30f)
 
 struct CamDev { float ox, oy, oz, hx, hy, hz, vx, vy, vz, lx, ly, lz; };
 
@@ -55,6 +59,15 @@ __device__ __forceinline__ uint32_t lane_id() {
 // number of set bits of a 64-bit lane mask below the calling lane (exclusive prefix count)
 __device__ __forceinline__ uint32_t prefix_count(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// n / d for a divisor fixed per launch: multiply-high by a precomputed magic (branch-free round-up method of
+// Granlund & Montgomery as used by libdivide); exact for every 32-bit n.  d == 1 is encoded as shift == 0xFFFFFFFF.
+struct FastDiv { uint32_t magic, shift; };
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+    if (f.shift == 0xFFFFFFFFu) return n;                           // wave-uniform
+    const uint32_t q = __umulhi(f.magic, n);
+    return (((n - q) >> 1) + q) >> f.shift;
 }
 
 // random_v1.glsl:22-31, :37-52
@@ -186,6 +199,7 @@ struct TraceArgs {
     CamDev cam;
     float lens_radius, lux, luy, luz, lvx, lvy, lvz;
     uint32_t width, height, spp, max_depth, seed, flags, edge;
+    FastDiv div_npix, div_width, div_edge, div_tile_rows;
     float t_min;
     uint32_t tile_rows, tile_index, tile_count;
     uint32_t npix;           // pixels owned by this shard
@@ -204,22 +218,22 @@ struct Path {
 
 __device__ __forceinline__ uint32_t frame_row(const TraceArgs& A, uint32_t local_row) {
     if (A.tile_count <= 1) return local_row;
-    const uint32_t lb = local_row / A.tile_rows, in = local_row - lb * A.tile_rows;
+    const uint32_t lb = fdiv(local_row, A.div_tile_rows), in = local_row - lb * A.tile_rows;
     return (lb * A.tile_count + A.tile_index) * A.tile_rows + in;
 }
 
 // sample -> primary ray (raytracer_v4.glsl:190-214 with the jitter in pixel units), unit direction
 __device__ __forceinline__ void start_path(const TraceArgs& A, uint32_t item, Path& P) {
-    const uint32_t sb = item / A.npix, pix = item - sb * A.npix;
+    const uint32_t sb = fdiv(item, A.div_npix), pix = item - sb * A.npix;
     const uint32_t s = A.s0 + sb;
-    const uint32_t lrow = pix / A.width, x = pix - lrow * A.width;
+    const uint32_t lrow = fdiv(pix, A.div_width), x = pix - lrow * A.width;
     const uint32_t y = frame_row(A, lrow);
     const uint32_t base = hash2(y * A.width + x, hash2(s, A.seed));
     float jx = 0.0f, jy = 0.0f;
     if (A.spp > 1) {
         const float xi0 = rnd(base, 1), xi1 = rnd(base, 2);
         if (A.edge != 0) {
-            const uint32_t sy = s / A.edge, sx = s - sy * A.edge;
+            const uint32_t sy = fdiv(s, A.div_edge), sx = s - sy * A.edge;
             jx = ((float)sx + xi0) / (float)A.edge - 0.5f;
             jy = ((float)sy + xi1) / (float)A.edge - 0.5f;
         } else { jx = xi0 - 0.5f; jy = xi1 - 0.5f; }
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
     const uint32_t tid = threadIdx.x, lane = lane_id();
 
     if (!MULTI_TILE) {                                              // whole scene fits: stage once
-        for (uint32_t k = tid; k < A.n_sph; k += kBlock) s_sph[k] = A.sph[k];
+        for (uint32_t k = tid; k < A.sph_tile; k += kBlock) s_sph[k] = k < A.n_sph ? A.sph[k] : kPadSphere;
         for (uint32_t k = tid; k < A.n_tri * 4; k += kBlock) s_tri[k] = A.tri[k];
         __syncthreads();
     }
@@ -338,13 +352,15 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
             const uint32_t cnt = min(A.sph_tile, A.n_sph - t0);
             if (MULTI_TILE) {
                 __syncthreads();
-                for (uint32_t k = tid; k < cnt; k += kBlock) s_sph[k] = A.sph[t0 + k];
+                for (uint32_t k = tid; k < A.sph_tile; k += kBlock) s_sph[k] = k < cnt ? A.sph[t0 + k] : kPadSphere;
                 __syncthreads();
             }
             if (alive) {
                 uint32_t ncand = 0;
-                // exact roots only for the few spheres whose line the ray can reach: candidates are queued in LDS
-                // and evaluated afterwards by all lanes together, keeping the hot loop free of divergent sqrt work.
+                // Exact roots are computed only for the few spheres whose line the ray crosses.  The hot loop is
+                // branch-free: 10 FMA-class ops give the discriminant, one v_alignbit shifts its sign bit into a
+                // per-lane mask (32 spheres per mask).  Lanes then queue their candidates in LDS and all lanes
+                // evaluate their own queues together, in ascending sphere index (ties keep the lower index).
                 auto flush = [&]() {
                     for (uint32_t q = 0; q < ncand; q++) {
                         const uint32_t j = cand[q * kBlock + tid];
@@ -352,26 +368,41 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
                         const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
                         const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
                         const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
-                        const float sq = __builtin_sqrtf(fma_(h, h, -c));
+                        const float disc = fma_(h, h, -c);
+                        if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) continue;   // the exact candidate rule
+                        const float sq = __builtin_sqrtf(disc);
                         float t = h - sq;
                         if (!(t > A.t_min)) t = h + sq;
                         if (t > A.t_min && t < tbest) { tbest = t; ibest = t0 + j; kind = 2; }
                     }
                     ncand = 0;
                 };
-#pragma unroll 4
-                for (uint32_t j = 0; j < cnt; j++) {
-                    const float4 s = s_sph[j];                      // wave-uniform address: LDS broadcast
-                    const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-                    const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
-                    const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
-                    const float disc = fma_(h, h, -c);
-                    if ((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f))) {
+                // N consecutive spheres: sign bits of the discriminants end up in the low N bits of `neg`
+                // (bit N-1-k <-> sphere b0+k), the bits above stay set; candidates are pushed in ascending index.
+                auto block = [&](uint32_t b0, auto n_tag) {
+                    constexpr uint32_t N = decltype(n_tag)::value;
+                    uint32_t neg = 0xFFFFFFFFu;
+#pragma unroll
+                    for (uint32_t k = 0; k < N; k++) {
+                        const float4 s = s_sph[b0 + k];             // wave-uniform address: LDS broadcast
+                        const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+                        const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+                        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+                        const float disc = fma_(h, h, -c);
+                        neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(disc), 31);
+                    }
+                    uint32_t cm = ~neg;
+                    while (cm != 0) {
+                        const uint32_t top = 31u - (uint32_t)__builtin_clz(cm);
+                        cm &= ~(1u << top);
                         if (ncand == kCandSlots) flush();
-                        cand[ncand * kBlock + tid] = j;
+                        cand[ncand * kBlock + tid] = b0 + (N - 1u - top);
                         ncand++;
                     }
-                }
+                };
+                uint32_t b0 = 0;                                    // tiles are padded to a multiple of 4 with never-hit spheres
+                for (; b0 + 32 <= cnt; b0 += 32) block(b0, std::integral_constant<uint32_t, 32>());
+                for (; b0 < cnt; b0 += 4) block(b0, std::integral_constant<uint32_t, 4>());
                 flush();
             }
         }
@@ -597,6 +628,46 @@ int take_event_pair(rt3_ctx* ctx, hipEvent_t* a, hipEvent_t* b) {
     return 0;
 }
 
+FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{ 0u, 0xFFFFFFFFu };
+    if (d <= 1) return f;
+    const uint32_t p = 31u - (uint32_t)__builtin_clz(d);
+    if ((d & (d - 1)) == 0) { f.magic = 0; f.shift = p - 1; return f; }
+    const uint64_t num = 1ull << (32 + p);
+    uint64_t m = num / d;
+    const uint64_t rem = num % d;
+    m += m;
+    const uint64_t twice = rem + rem;
+    if (twice >= d) m += 1;
+    f.magic = (uint32_t)(m + 1);
+    f.shift = p;
+    return f;
+}
+uint32_t fastdiv_host(uint32_t n, FastDiv f) {
+    if (f.shift == 0xFFFFFFFFu) return n;
+    const uint32_t q = (uint32_t)(((uint64_t)f.magic * n) >> 32);
+    return (((n - q) >> 1) + q) >> f.shift;
+}
+// exhaustive near multiples + a pseudo-random sweep; a wrong magic would silently shift pixels
+bool fastdiv_ok(uint32_t d, uint32_t n_max) {
+    if (d == 0) return false;
+    const FastDiv f = make_fastdiv(d);
+    uint32_t x = 0x9E3779B9u;
+    for (uint32_t i = 0; i < 4096; i++) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        const uint32_t n = x % (n_max + 1u);
+        if (fastdiv_host(n, f) != n / d) return false;
+    }
+    for (uint64_t k = 0; k <= 64 && k * d <= n_max; k++) {
+        const uint64_t m = (uint64_t)(n_max / d - k) * d;
+        for (int o = -1; o <= 1; o++) {
+            const int64_t n = (int64_t)m + o;
+            if (n >= 0 && n <= (int64_t)n_max && fastdiv_host((uint32_t)n, f) != (uint32_t)n / d) return false;
+        }
+    }
+    return true;
+}
+
 bool row_owned(const rt3_params* p, uint32_t y) {
     if (p->tile_count <= 1) return true;
     return ((y / p->tile_rows) % p->tile_count) == p->tile_index;
@@ -805,7 +876,7 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     A.sph = ctx->d_sph; A.sph_invr = ctx->d_sph_invr; A.sph_mat = ctx->d_sph_mat; A.sph_kind = ctx->d_sph_kind; A.n_sph = ctx->n_sph;
     A.tri = ctx->d_tri; A.tri_mat = ctx->d_tri_mat; A.tri_kind = ctx->d_tri_kind; A.n_tri = ctx->n_faces;
     const bool multi = ctx->n_sph > kSphTileMax || ctx->n_faces > kTriTileMax;
-    A.sph_tile = std::max(1u, std::min(ctx->n_sph, kSphTileMax));
+    A.sph_tile = ((std::max(1u, std::min(ctx->n_sph, kSphTileMax)) + 3u) / 4u) * 4u;       // whole 4-sphere mask blocks
     A.tri_tile = std::max(1u, std::min(ctx->n_faces, kTriTileMax));
     A.cam = cam_dev(cam);
     A.lens_radius = p->lens_radius;
@@ -826,6 +897,11 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     A.t_min = p->t_min;
     A.tile_rows = p->tile_rows; A.tile_index = p->tile_index; A.tile_count = p->tile_count;
     A.npix = npix;
+    A.div_npix = make_fastdiv(npix); A.div_width = make_fastdiv(p->width);
+    A.div_edge = make_fastdiv(A.edge ? A.edge : 1); A.div_tile_rows = make_fastdiv(p->tile_count > 1 ? p->tile_rows : 1);
+    if (!fastdiv_ok(npix, 0x7FFFFFFFu) || !fastdiv_ok(p->width, 0x7FFFFFFFu) || !fastdiv_ok(A.edge ? A.edge : 1, p->spp) ||
+        !fastdiv_ok(p->tile_count > 1 ? p->tile_rows : 1, p->height))
+        return fail(ctx, RT3_E_DEVICE, "internal: magic-number division self-check failed");
     A.rad = ctx->d_rad; A.work_counter = ctx->d_work; A.cast_counter = ctx->d_casts;
 
     const size_t lds_bytes = (size_t)kCandSlots * kBlock * 4 + (size_t)A.sph_tile * 16 + (size_t)(ctx->n_faces ? A.tri_tile : 0) * 64;
