@@ -33,7 +33,7 @@ constexpr int      kBlock       = 256;     // 4 wavefronts of 64
 constexpr int      kCandSlots   = 16;      // deferred sphere candidates per lane (LDS), flushed when full
 constexpr uint32_t kWorkChunk   = 256;     // samples a wave takes from the global queue per atomic
 constexpr uint32_t kSphTileMax  = 1024;    // spheres per LDS tile (16 KiB)
-constexpr uint32_t kTriTileMax  = 256;     // faces per LDS tile (4 x float4 = 16 KiB)
+constexpr uint32_t kTriTileMax  = 1024;    // face bounding spheres per LDS tile (16 KiB)
 constexpr uint32_t kModeRTile   = 512;     // faces per LDS tile in k_mode_r (32 KiB)
 
 // filler for the tail of a sphere tile: r^2 = -1e30 makes the discriminant negative for every ray
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_mode_r(const float4* __restrict__ tr
 // ------------------------------------------------------------------------------------------------------
 struct TraceArgs {
     const float4* sph;       const float* sph_invr;  const float4* sph_mat;  const uint32_t* sph_kind;  uint32_t n_sph;
-    const float4* tri;       const float4* tri_mat;  const uint32_t* tri_kind;                          uint32_t n_tri;
+    const float4* tri;       const float4* tri_mat;  const uint32_t* tri_kind;  const float4* tri_bound; uint32_t n_tri;
     uint32_t sph_tile, tri_tile;
     CamDev cam;
     float lens_radius, lux, luy, luz, lvx, lvy, lvz;
@@ -263,7 +263,53 @@ __device__ __forceinline__ void start_path(const TraceArgs& A, uint32_t item, Pa
     P.slot = item; P.base = base; P.depth = 0;
 }
 
-template <bool MULTI_TILE>
+// One LDS tile of bounding spheres (cx, cy, cz, r^2) against the ray of every lane — the hot loop of k_trace.
+// Per sphere: one broadcast ds_read_b128 + 10 FMA-class VALU ops giving the discriminant of the line-sphere quadratic,
+// and one v_alignbit_b32 that shifts its sign bit into a per-lane mask (32 spheres per mask; no branches, loads
+// batched).  MARGIN adds one fma that biases the discriminant by 1e-5*c, for spheres that only BOUND a primitive:
+// the test must never lose a true hit to rounding.  Lanes then push their candidate indices into a
+// per-lane LDS queue and `eval(j)` runs on every queued index, all lanes together, in ascending index order.
+template <bool MARGIN, class Eval>
+__device__ __forceinline__ void scan_tile(const float4* __restrict__ tile, uint32_t cnt, uint32_t* __restrict__ cand, uint32_t tid,
+                                          float ox, float oy, float oz, float dx, float dy, float dz, Eval&& eval) {
+    uint32_t ncand = 0;
+    auto flush = [&]() {
+        for (uint32_t q = 0; q < ncand; q++) eval(cand[q * kBlock + tid]);
+        ncand = 0;
+    };
+    // N consecutive spheres: the sign bits end up in the low N bits of `neg` (bit N-1-k <-> sphere b0+k), the bits
+    // above stay set; candidates are pushed in ascending index.
+    auto block = [&](uint32_t b0, auto n_tag) {
+        constexpr uint32_t N = decltype(n_tag)::value;
+        uint32_t neg = 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t k = 0; k < N; k++) {
+            const float4 s = tile[b0 + k];                          // wave-uniform address: LDS broadcast
+            const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+            const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+            const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+            float disc = fma_(h, h, -c);
+            if (MARGIN) disc = fma_(1e-5f, c, disc);
+            neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(disc), 31);
+        }
+        uint32_t cm = ~neg;
+        while (cm != 0) {
+            const uint32_t top = 31u - (uint32_t)__builtin_clz(cm);
+            cm &= ~(1u << top);
+            if (ncand == kCandSlots) flush();
+            cand[ncand * kBlock + tid] = b0 + (N - 1u - top);
+            ncand++;
+        }
+    };
+    uint32_t b0 = 0;                                                // tiles are padded to a multiple of 4 with never-hit spheres
+    for (; b0 + 32 <= cnt; b0 += 32) block(b0, std::integral_constant<uint32_t, 32>());
+    for (; b0 < cnt; b0 += 4) block(b0, std::integral_constant<uint32_t, 4>());
+    flush();
+}
+
+// HAS_TRI / HAS_SPH compile the face loop / sphere loop (and the matching shading) in or out, so that a sphere-only
+// scene does not pay registers or code for the triangle path.
+template <bool MULTI_TILE, bool HAS_TRI, bool HAS_SPH>
 __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
     extern __shared__ float4 lds[];
     uint32_t* cand = reinterpret_cast<uint32_t*>(lds);              // [kCandSlots][kBlock]
@@ -272,8 +318,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
     const uint32_t tid = threadIdx.x, lane = lane_id();
 
     if (!MULTI_TILE) {                                              // whole scene fits: stage once
-        for (uint32_t k = tid; k < A.sph_tile; k += kBlock) s_sph[k] = k < A.n_sph ? A.sph[k] : kPadSphere;
-        for (uint32_t k = tid; k < A.n_tri * 4; k += kBlock) s_tri[k] = A.tri[k];
+        if (HAS_SPH) for (uint32_t k = tid; k < A.sph_tile; k += kBlock) s_sph[k] = k < A.n_sph ? A.sph[k] : kPadSphere;
+        if (HAS_TRI) for (uint32_t k = tid; k < A.tri_tile; k += kBlock) s_tri[k] = k < A.n_tri ? A.tri_bound[k] : kPadSphere;
         __syncthreads();
     }
 
@@ -317,38 +363,44 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
         uint32_t ibest = 0, kind = 0;
         const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
 
-        for (uint32_t t0 = 0; t0 < A.n_tri; t0 += A.tri_tile) {     // hit_vertex, raytracer_v4.glsl:116-153
+        // Faces: hit_vertex, raytracer_v4.glsl:116-153 (= ray_color's test, SequentialRenderer.cpp:53-98, with the sign of
+        // n.o corrected).  The hot loop tests the ray against a slightly inflated bounding sphere of every face; the
+        // reference's plane + three-edge test, in its own operation order, runs only for the faces that survive.
+        for (uint32_t t0 = 0; HAS_TRI && t0 < A.n_tri; t0 += A.tri_tile) {
             const uint32_t cnt = min(A.tri_tile, A.n_tri - t0);
             if (MULTI_TILE) {
                 __syncthreads();
-                for (uint32_t k = tid; k < cnt * 4; k += kBlock) s_tri[k] = A.tri[(size_t)t0 * 4 + k];
+                for (uint32_t k = tid; k < A.tri_tile; k += kBlock) s_tri[k] = k < cnt ? A.tri_bound[t0 + k] : kPadSphere;
                 __syncthreads();
             }
             if (alive) {
-                for (uint32_t j = 0; j < cnt; j++) {
-                    const float4 n = s_tri[4 * j];
+                scan_tile<true>(s_tri, cnt, cand, tid, ox, oy, oz, dx, dy, dz, [&](uint32_t j) {
+                    const float4* f = A.tri + (size_t)(t0 + j) * 4;
+                    const float4 n = f[0];
                     const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
-                    if (nd == 0.0f) continue;
+                    if (nd == 0.0f) return;
                     const float t = (n.w - dot3(n.x, n.y, n.z, ox, oy, oz)) / nd;
-                    if (!(t >= A.t_min && t < tbest)) continue;
-                    const float4 p1 = s_tri[4 * j + 1], p2 = s_tri[4 * j + 2], p3 = s_tri[4 * j + 3];
+                    if (!(t >= A.t_min && t < tbest)) return;
+                    const float4 p1 = f[1], p2 = f[2], p3 = f[3];
                     const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
                     float ex, ey, ez, qx, qy, qz, cx, cy, cz;
                     ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
                     cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
                     ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
                     cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
                     ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
                     cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) continue;
+                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
                     tbest = t; ibest = t0 + j; kind = 1;
-                }
+                });
             }
         }
 
-        for (uint32_t t0 = 0; t0 < A.n_sph; t0 += A.sph_tile) {     // hit_sphere, raytracer_v4.glsl:157-178, unit d
+        // Analytic spheres: hit_sphere, raytracer_v4.glsl:157-178 with a unit direction.  Exact roots only for the few
+        // spheres whose line the ray crosses; the exact candidate rule of DESIGN.md §4.4 is re-checked there.
+        for (uint32_t t0 = 0; HAS_SPH && t0 < A.n_sph; t0 += A.sph_tile) {
             const uint32_t cnt = min(A.sph_tile, A.n_sph - t0);
             if (MULTI_TILE) {
                 __syncthreads();
@@ -356,54 +408,18 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
                 __syncthreads();
             }
             if (alive) {
-                uint32_t ncand = 0;
-                // Exact roots are computed only for the few spheres whose line the ray crosses.  The hot loop is
-                // branch-free: 10 FMA-class ops give the discriminant, one v_alignbit shifts its sign bit into a
-                // per-lane mask (32 spheres per mask).  Lanes then queue their candidates in LDS and all lanes
-                // evaluate their own queues together, in ascending sphere index (ties keep the lower index).
-                auto flush = [&]() {
-                    for (uint32_t q = 0; q < ncand; q++) {
-                        const uint32_t j = cand[q * kBlock + tid];
-                        const float4 s = s_sph[j];
-                        const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-                        const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
-                        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
-                        const float disc = fma_(h, h, -c);
-                        if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) continue;   // the exact candidate rule
-                        const float sq = __builtin_sqrtf(disc);
-                        float t = h - sq;
-                        if (!(t > A.t_min)) t = h + sq;
-                        if (t > A.t_min && t < tbest) { tbest = t; ibest = t0 + j; kind = 2; }
-                    }
-                    ncand = 0;
-                };
-                // N consecutive spheres: sign bits of the discriminants end up in the low N bits of `neg`
-                // (bit N-1-k <-> sphere b0+k), the bits above stay set; candidates are pushed in ascending index.
-                auto block = [&](uint32_t b0, auto n_tag) {
-                    constexpr uint32_t N = decltype(n_tag)::value;
-                    uint32_t neg = 0xFFFFFFFFu;
-#pragma unroll
-                    for (uint32_t k = 0; k < N; k++) {
-                        const float4 s = s_sph[b0 + k];             // wave-uniform address: LDS broadcast
-                        const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-                        const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
-                        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
-                        const float disc = fma_(h, h, -c);
-                        neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(disc), 31);
-                    }
-                    uint32_t cm = ~neg;
-                    while (cm != 0) {
-                        const uint32_t top = 31u - (uint32_t)__builtin_clz(cm);
-                        cm &= ~(1u << top);
-                        if (ncand == kCandSlots) flush();
-                        cand[ncand * kBlock + tid] = b0 + (N - 1u - top);
-                        ncand++;
-                    }
-                };
-                uint32_t b0 = 0;                                    // tiles are padded to a multiple of 4 with never-hit spheres
-                for (; b0 + 32 <= cnt; b0 += 32) block(b0, std::integral_constant<uint32_t, 32>());
-                for (; b0 < cnt; b0 += 4) block(b0, std::integral_constant<uint32_t, 4>());
-                flush();
+                scan_tile<false>(s_sph, cnt, cand, tid, ox, oy, oz, dx, dy, dz, [&](uint32_t j) {
+                    const float4 s = s_sph[j];
+                    const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+                    const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+                    const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+                    const float disc = fma_(h, h, -c);
+                    if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return;
+                    const float sq = __builtin_sqrtf(disc);
+                    float t = h - sq;
+                    if (!(t > A.t_min)) t = h + sq;
+                    if (t > A.t_min && t < tbest) { tbest = t; ibest = t0 + j; kind = 2; }
+                });
             }
         }
 
@@ -420,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
             } else {
                 float4 m; uint32_t mk;
                 float px, py, pz, nx, ny, nz;
-                if (kind == 1) {
+                if (HAS_TRI && (!HAS_SPH || kind == 1)) {
                     m = A.tri_mat[ibest]; mk = A.tri_kind[ibest];
                     const float4 n = A.tri[(size_t)ibest * 4];
                     px = ox + tbest * dx; py = oy + tbest * dy; pz = oz + tbest * dz;
@@ -555,7 +571,7 @@ struct rt3_ctx {
 
     // mesh
     uint32_t n_faces = 0;
-    float4* d_tri = nullptr; float4* d_tri_mat = nullptr; uint32_t* d_tri_kind = nullptr;
+    float4* d_tri = nullptr; float4* d_tri_mat = nullptr; uint32_t* d_tri_kind = nullptr; float4* d_tri_bound = nullptr;
     // spheres
     uint32_t n_sph = 0;
     float4* d_sph = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
@@ -668,6 +684,24 @@ bool fastdiv_ok(uint32_t d, uint32_t n_max) {
     return true;
 }
 
+// Bounding sphere of a face for the hot loop: centroid + largest vertex distance (double), inflated by 0.1 % plus an
+// absolute term that scales with the coordinates, so that neither the rounding of the centre to float nor the float
+// noise of the exact plane/edge test can place an accepted hit outside it.  r^2 is rounded up.
+float4 face_bound(const float* p1, const float* p2, const float* p3) {
+    const double cx = ((double)p1[0] + p2[0] + p3[0]) / 3.0, cy = ((double)p1[1] + p2[1] + p3[1]) / 3.0, cz = ((double)p1[2] + p2[2] + p3[2]) / 3.0;
+    double r2 = 0.0, big = 0.0;
+    for (const float* p : { p1, p2, p3 }) {
+        const double ddx = p[0] - cx, ddy = p[1] - cy, ddz = p[2] - cz;
+        r2 = std::max(r2, ddx * ddx + ddy * ddy + ddz * ddz);
+        big = std::max(big, std::max(std::fabs((double)p[0]), std::max(std::fabs((double)p[1]), std::fabs((double)p[2]))));
+    }
+    const double r = std::sqrt(r2) * 1.001 + 1e-5 * (1.0 + big);
+    float r2f = (float)(r * r);
+    if ((double)r2f < r * r) r2f = std::nextafter(r2f, INFINITY);
+    if (!(r2f >= 0.0f)) r2f = INFINITY;                             // NaN / inf vertices: always a candidate, the exact test decides
+    return make_float4((float)cx, (float)cy, (float)cz, r2f);
+}
+
 bool row_owned(const rt3_params* p, uint32_t y) {
     if (p->tile_count <= 1) return true;
     return ((y / p->tile_rows) % p->tile_count) == p->tile_index;
@@ -726,7 +760,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = { ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_sph, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
+    void* bufs[] = { ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_sph, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_out, ctx->d_work, ctx->d_casts };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -751,7 +785,7 @@ int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const f
     if (n_faces != 0 && (!faces || !vertices)) return fail(ctx, RT3_E_ARG, "faces / vertices is NULL");
     RT3_HIP(hipSetDevice(ctx->device));
     // de-index into 4 x float4 per face, in face order (order defines tie-breaking: SequentialRenderer.cpp:71)
-    std::vector<float4> tri((size_t)n_faces * 4), mat(n_faces);
+    std::vector<float4> tri((size_t)n_faces * 4), mat(n_faces), bound(n_faces);
     std::vector<uint32_t> kind(n_faces);
     for (uint32_t i = 0; i < n_faces; i++) {
         const rt3_gface& f = faces[i];
@@ -765,6 +799,7 @@ int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const f
         tri[4 * (size_t)i + 1] = make_float4(p1[0], p1[1], p1[2], 0.0f);
         tri[4 * (size_t)i + 2] = make_float4(p2[0], p2[1], p2[2], 0.0f);
         tri[4 * (size_t)i + 3] = make_float4(p3[0], p3[1], p3[2], 0.0f);
+        bound[i] = face_bound(p1, p2, p3);
         if (face_materials) {
             const rt3_material& m = face_materials[i];
             if (m.kind > RT3_MAT_DIELECTRIC) return fail(ctx, RT3_E_ARG, "unknown material kind");
@@ -776,7 +811,8 @@ int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const f
         }
     }
     int rc;
-    if ((rc = upload(ctx, &ctx->d_tri, tri)) || (rc = upload(ctx, &ctx->d_tri_mat, mat)) || (rc = upload(ctx, &ctx->d_tri_kind, kind)))
+    if ((rc = upload(ctx, &ctx->d_tri, tri)) || (rc = upload(ctx, &ctx->d_tri_mat, mat)) || (rc = upload(ctx, &ctx->d_tri_kind, kind)) ||
+        (rc = upload(ctx, &ctx->d_tri_bound, bound)))
         return rc;
     ctx->n_faces = n_faces;
     return 0;
@@ -874,10 +910,10 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     TraceArgs A;
     std::memset(&A, 0, sizeof A);
     A.sph = ctx->d_sph; A.sph_invr = ctx->d_sph_invr; A.sph_mat = ctx->d_sph_mat; A.sph_kind = ctx->d_sph_kind; A.n_sph = ctx->n_sph;
-    A.tri = ctx->d_tri; A.tri_mat = ctx->d_tri_mat; A.tri_kind = ctx->d_tri_kind; A.n_tri = ctx->n_faces;
+    A.tri = ctx->d_tri; A.tri_mat = ctx->d_tri_mat; A.tri_kind = ctx->d_tri_kind; A.tri_bound = ctx->d_tri_bound; A.n_tri = ctx->n_faces;
     const bool multi = ctx->n_sph > kSphTileMax || ctx->n_faces > kTriTileMax;
     A.sph_tile = ((std::max(1u, std::min(ctx->n_sph, kSphTileMax)) + 3u) / 4u) * 4u;       // whole 4-sphere mask blocks
-    A.tri_tile = std::max(1u, std::min(ctx->n_faces, kTriTileMax));
+    A.tri_tile = ((std::max(1u, std::min(ctx->n_faces, kTriTileMax)) + 3u) / 4u) * 4u;
     A.cam = cam_dev(cam);
     A.lens_radius = p->lens_radius;
     {
@@ -904,10 +940,14 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
         return fail(ctx, RT3_E_DEVICE, "internal: magic-number division self-check failed");
     A.rad = ctx->d_rad; A.work_counter = ctx->d_work; A.cast_counter = ctx->d_casts;
 
-    const size_t lds_bytes = (size_t)kCandSlots * kBlock * 4 + (size_t)A.sph_tile * 16 + (size_t)(ctx->n_faces ? A.tri_tile : 0) * 64;
+    const size_t lds_bytes = (size_t)kCandSlots * kBlock * 4 + (size_t)A.sph_tile * 16 + (size_t)(ctx->n_faces ? A.tri_tile : 0) * 16;
+    using TraceKernel = void (*)(const TraceArgs);
+    const bool has_tri = ctx->n_faces > 0, has_sph = ctx->n_sph > 0;
+    TraceKernel kernel = nullptr;
+    if (!multi) kernel = has_tri ? (has_sph ? k_trace<false, true, true> : k_trace<false, true, false>) : k_trace<false, false, true>;
+    else        kernel = has_tri ? (has_sph ? k_trace<true, true, true> : k_trace<true, true, false>) : k_trace<true, false, true>;
     int per_cu = 0;
-    if (multi) RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<true>, kBlock, lds_bytes));
-    else       RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<false>, kBlock, lds_bytes));
+    RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes));
     if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_trace does not fit on a CU");
     per_cu = std::min(per_cu, 8);
 
@@ -921,8 +961,7 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
         if ((rc = take_event_pair(ctx, &a, &b))) return rc;
         RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
         RT3_HIP(hipEventRecord(a, stream));
-        if (multi) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
-        else       hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipEventRecord(b, stream));
         hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
