@@ -22,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: must be set before HIP initialises (RCCL)
 
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 512, 50
 SCENE_SEED, RENDER_SEED = 42, 1
@@ -111,7 +112,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     rt3 = importlib.import_module("raytracer-3_amd")

@@ -198,6 +198,9 @@ float    rt3_random_float(uint32_t m);
 /* Debug probe used by the parity tests only: element-wise DEVICE arithmetic on n inputs —
  * div = a/b, sq = sqrt(|a|), fm = fma(a,b,a), (cs,sn) = sincos2pi(frac bits of a), sk3 = sky(a,b,-2) (3 per
  * element), pk = pack(a,b,u).  Lets the tests prove the device's IEEE behaviour matches the host's. */
+/* Debug switch used by the parity tests only: non-zero makes rt3_render* always take the plain brute-force Mode-R kernel
+ * instead of the bounding-sphere-filtered one (both must give identical pixels). */
+int      rt3_debug_force_plain_mode_r(rt3_ctx* ctx, int on);
 int      rt3_debug_arith(rt3_ctx* ctx, const float* a, const float* b, uint32_t n, float* div, float* sq, float* fm,
                          float* cs, float* sn, float* sk3, uint32_t* pk);
 

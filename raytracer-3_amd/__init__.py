@@ -27,7 +27,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt3hip.so")
+LIB_PATH = os.environ.get("RT3_LIB_PATH", os.path.join(_HERE, "librt3hip.so"))      # override: A/B two builds
 
 # --------------------------------------------------------------------------------------------------------
 # wire structs (include/rt3.h)
@@ -69,7 +69,7 @@ EXPORTS = [
     "rt3_sphere_vertex_count", "rt3_prerender_sphere", "rt3_object_count", "rt3_prerender_object",
     "rt3_transfer_entity", "rt3_camera_update", "rt3_camera_look_at", "rt3_frame_ppm_bytes", "rt3_frame_to_ppm",
     "rt3_scene_three_spheres", "rt3_scene_weekend", "rt3_scene_stress", "rt3_scene_cornell", "rt3_hash_u32",
-    "rt3_random_float", "rt3_debug_arith",
+    "rt3_random_float", "rt3_debug_arith", "rt3_debug_force_plain_mode_r",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def lib():
         "rt3_scene_stress": (u32, [u32, u32, vp, vp, u32]), "rt3_scene_cornell": (u32, [u32, vp, vp, vp, u32]),
         "rt3_hash_u32": (u32, [u32]), "rt3_random_float": (f32, [u32]),
         "rt3_debug_arith": (i32, [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]),
+        "rt3_debug_force_plain_mode_r": (i32, [vp, i32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -498,6 +499,9 @@ class HipRenderer(Renderer):
         s = rt3_stats()
         self._check(lib().rt3_get_stats(self._ctx, C.byref(s)))
         return s
+
+    def force_plain_mode_r(self, on):
+        self._check(lib().rt3_debug_force_plain_mode_r(self._ctx, 1 if on else 0))
 
     def debug_arith(self, a, b):
         a = np.ascontiguousarray(a, np.float32)

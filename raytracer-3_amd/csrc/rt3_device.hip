@@ -307,6 +307,65 @@ __device__ __forceinline__ void scan_tile(const float4* __restrict__ tile, uint3
     flush();
 }
 
+// Mode R with the camera at the origin (the only camera Camera::update can build, Camera.cpp:89): n.o == 0, so the
+// reference's hit point lies on the ray's line and the bounding-sphere scan is a valid conservative filter.  The
+// reference's own test (same code as k_mode_r) runs on the surviving faces, in ascending face index.
+__global__ __launch_bounds__(kBlock) void k_mode_r_fast(const float4* __restrict__ tri, const float4* __restrict__ tri_bound,
+                                                       const float4* __restrict__ face_rgb, uint32_t n_faces, CamDev cam,
+                                                       uint32_t width, uint32_t height, uint32_t* __restrict__ out) {
+    __shared__ float4 tile[kTriTileMax];
+    __shared__ uint32_t cand[kCandSlots * kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pixel = blockIdx.x * kBlock + tid;
+    const bool valid = pixel < width * height;
+    const uint32_t x = valid ? pixel % width : 0u, y = valid ? pixel / width : 0u;
+    const float u = (float)((double)(float)x / ((double)(float)width - 1.0));
+    const float v = (float)((double)(float)(height - 1 - y) / ((double)(float)height - 1.0));
+    const float ox = cam.ox, oy = cam.oy, oz = cam.oz;              // all zero (checked by the host)
+    const float dx = ((cam.lx + u * cam.hx) + v * cam.vx) - ox;
+    const float dy = ((cam.ly + u * cam.hy) + v * cam.vy) - oy;
+    const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
+    const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));     // unit direction for the filter only
+    const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+
+    uint32_t min_i = 0;
+    float min_t = __builtin_inff();
+    for (uint32_t t0 = 0; t0 < n_faces; t0 += kTriTileMax) {
+        const uint32_t cnt = min(kTriTileMax, n_faces - t0);
+        __syncthreads();
+        for (uint32_t k = tid; k < kTriTileMax; k += kBlock) tile[k] = k < cnt ? tri_bound[t0 + k] : kPadSphere;
+        __syncthreads();
+        if (!valid) continue;
+        scan_tile<true>(tile, cnt, cand, tid, ox, oy, oz, ux, uy, uz, [&](uint32_t j) {
+            const float4* f = tri + (size_t)(t0 + j) * 4;
+            const float4 n = f[0];
+            const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);       // SequentialRenderer.cpp:56
+            if (nd == 0.0f) return;
+            const float t = (dot3(n.x, n.y, n.z, ox, oy, oz) + n.w) / nd;      // :70
+            if (t < 0.0f || t >= min_t) return;                     // :71
+            const float4 p1 = f[1], p2 = f[2], p3 = f[3];
+            const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+            float ex, ey, ez, qx, qy, qz, cx, cy, cz;
+            ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            min_i = t0 + j;
+            min_t = t;
+        });
+    }
+    if (!valid) return;
+    float r, g, b;
+    if (min_t < __builtin_inff()) { const float4 c = face_rgb[min_i]; r = c.x; g = c.y; b = c.z; }
+    else sky(dx, dy, dz, r, g, b);
+    out[pixel] = pack_pixel(r, g, b);
+}
+
 // HAS_TRI / HAS_SPH compile the face loop / sphere loop (and the matching shading) in or out, so that a sphere-only
 // scene does not pay registers or code for the triangle path.
 template <bool MULTI_TILE, bool HAS_TRI, bool HAS_SPH>
@@ -583,6 +642,7 @@ struct rt3_ctx {
     uint32_t* d_work = nullptr;                                     // [0] work counter
     unsigned long long* d_casts = nullptr;
     uint64_t rad_cap_bytes = 16ull << 30;
+    bool force_plain_mode_r = false;                                // tests: compare the two Mode-R kernels
 
     // stats of the last render
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;              // per dominant-kernel launch
@@ -779,6 +839,12 @@ int rt3_set_sample_storage_cap(rt3_ctx* ctx, uint64_t bytes) {
     return 0;
 }
 
+int rt3_debug_force_plain_mode_r(rt3_ctx* ctx, int on) {
+    if (!ctx) return RT3_E_ARG;
+    ctx->force_plain_mode_r = on != 0;
+    return 0;
+}
+
 int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const float* vertices, uint32_t n_vertices,
                  const rt3_material* face_materials) {
     if (!ctx) return RT3_E_ARG;
@@ -855,8 +921,15 @@ int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint3
     const uint32_t npix = width * height;
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
     RT3_HIP(hipEventRecord(a, stream));
-    hipLaunchKernelGGL(k_mode_r, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                       ctx->d_tri, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
+    // k_mode_r_fast needs n.o == 0 exactly (camera at the origin, as Camera::update always builds it) and finite rays;
+    // any other camera takes the plain brute-force kernel, which reproduces the reference for every input.
+    const bool at_origin = cam->origin[0] == 0.0f && cam->origin[1] == 0.0f && cam->origin[2] == 0.0f;
+    if (at_origin && !ctx->force_plain_mode_r)
+        hipLaunchKernelGGL(k_mode_r_fast, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                           ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
+    else
+        hipLaunchKernelGGL(k_mode_r, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
+                           ctx->d_tri, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
     RT3_HIP(hipGetLastError());
     RT3_HIP(hipEventRecord(b, stream));
     RT3_HIP(hipEventRecord(ctx->ev_end, stream));

@@ -38,6 +38,20 @@ def test_builtin_scene_reproduces_the_reference_ppm(rt3, renderer, oracle, size)
     assert st.prim_tests == w * h * len(faces) and st.trace_ms > 0
 
 
+def test_plain_and_filtered_kernels_agree(rt3, renderer, oracle):
+    """k_mode_r (brute force, any camera) and k_mode_r_fast (bounding-sphere filter, camera at the origin) give the
+    same pixels; the filter is conservative, the exact test is the reference's in both."""
+    faces, verts = load_builtin_scene()
+    fast = hip_mode_r(rt3, renderer, faces, verts, 640, 360)
+    renderer.force_plain_mode_r(True)
+    try:
+        plain = hip_mode_r(rt3, renderer, faces, verts, 640, 360)
+    finally:
+        renderer.force_plain_mode_r(False)
+    assert np.array_equal(fast, plain)
+    assert np.array_equal(fast, oracle.render_mode_r(faces, verts, oracle.camera_update(640, 360), 640, 360))
+
+
 def test_small_goldens(rt3, renderer, oracle):
     z = np.load(os.path.join(GOLDEN, "mode_r_small.npz"))
     tri = oracle.prerender_triangle((1.0, 0.0, -3.0), (-1.0, 0.0, -3.0), (0.0, 1.0, -3.0), (1.0, 0.0, 0.0))
