@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -32,8 +33,7 @@ namespace {
 constexpr int      kBlock       = 256;     // 4 wavefronts of 64
 constexpr int      kCandSlots   = 16;      // deferred sphere candidates per lane (LDS), flushed when full
 constexpr uint32_t kWorkChunk   = 256;     // samples a wave takes from the global queue per atomic
-constexpr uint32_t kSphTileMax  = 1024;    // spheres per LDS tile (16 KiB)
-constexpr uint32_t kTriTileMax  = 1024;    // face bounding spheres per LDS tile (16 KiB)
+constexpr uint32_t kSphLdsMax   = 2048;    // spheres mirrored in LDS for the exact-evaluation gathers (32 KiB)
 constexpr uint32_t kModeRTile   = 512;     // faces per LDS tile in k_mode_r (32 KiB)
 
 // filler for the tail of a sphere tile: r^2 = -1e30 makes the discriminant negative for every ray
@@ -195,7 +195,6 @@ __global__ __launch_bounds__(kBlock) void k_mode_r(const float4* __restrict__ tr
 struct TraceArgs {
     const float4* sph;       const float* sph_invr;  const float4* sph_mat;  const uint32_t* sph_kind;  uint32_t n_sph;
     const float4* tri;       const float4* tri_mat;  const uint32_t* tri_kind;  const float4* tri_bound; uint32_t n_tri;
-    uint32_t sph_tile, tri_tile;
     CamDev cam;
     float lens_radius, lux, luy, luz, lvx, lvy, lvz;
     uint32_t width, height, spp, max_depth, seed, flags, edge;
@@ -269,28 +268,41 @@ __device__ __forceinline__ void start_path(const TraceArgs& A, uint32_t item, Pa
 // batched).  MARGIN adds one fma that biases the discriminant by 1e-5*c, for spheres that only BOUND a primitive:
 // the test must never lose a true hit to rounding.  Lanes then push their candidate indices into a
 // per-lane LDS queue and `eval(j)` runs on every queued index, all lanes together, in ascending index order.
+// read-only scene data is addressed through the constant address space: wave-uniform loads from it become scalar
+// (s_load_dwordx16 = 4 spheres per instruction, served by the scalar cache) and their results are SGPR operands.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) f32x4* scene_ptr;
+__device__ __forceinline__ scene_ptr as_scene(const float4* p) { return (scene_ptr)p; }
+
 template <bool MARGIN, class Eval>
-__device__ __forceinline__ void scan_tile(const float4* __restrict__ tile, uint32_t cnt, uint32_t* __restrict__ cand, uint32_t tid,
+__device__ __forceinline__ void scan_tile(scene_ptr tile, uint32_t cnt, uint32_t* __restrict__ cand, uint32_t tid,
                                           float ox, float oy, float oz, float dx, float dy, float dz, Eval&& eval) {
     uint32_t ncand = 0;
     auto flush = [&]() {
         for (uint32_t q = 0; q < ncand; q++) eval(cand[q * kBlock + tid]);
         ncand = 0;
     };
+    auto test = [&](const f32x4 s, uint32_t neg) {
+        const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+        const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+        float disc = fma_(h, h, -c);
+        if (MARGIN) disc = fma_(1e-5f, c, disc);
+        return __builtin_amdgcn_alignbit(neg, __float_as_uint(disc), 31);
+    };
     // N consecutive spheres: the sign bits end up in the low N bits of `neg` (bit N-1-k <-> sphere b0+k), the bits
-    // above stay set; candidates are pushed in ascending index.
+    // above stay set; candidates are pushed in ascending index.  Groups of 4 spheres (one 64-byte scalar load) are
+    // fetched one group ahead of the arithmetic.
     auto block = [&](uint32_t b0, auto n_tag) {
         constexpr uint32_t N = decltype(n_tag)::value;
         uint32_t neg = 0xFFFFFFFFu;
+        f32x4 g0 = tile[b0], g1 = tile[b0 + 1], g2 = tile[b0 + 2], g3 = tile[b0 + 3];
 #pragma unroll
-        for (uint32_t k = 0; k < N; k++) {
-            const float4 s = tile[b0 + k];                          // wave-uniform address: LDS broadcast
-            const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-            const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
-            const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
-            float disc = fma_(h, h, -c);
-            if (MARGIN) disc = fma_(1e-5f, c, disc);
-            neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(disc), 31);
+        for (uint32_t k = 0; k < N; k += 4) {
+            f32x4 n0 = g0, n1 = g1, n2 = g2, n3 = g3;
+            if (k + 4 < N) { n0 = tile[b0 + k + 4]; n1 = tile[b0 + k + 5]; n2 = tile[b0 + k + 6]; n3 = tile[b0 + k + 7]; }
+            neg = test(g0, neg); neg = test(g1, neg); neg = test(g2, neg); neg = test(g3, neg);
+            g0 = n0; g1 = n1; g2 = n2; g3 = n3;
         }
         uint32_t cm = ~neg;
         while (cm != 0) {
@@ -301,7 +313,7 @@ __device__ __forceinline__ void scan_tile(const float4* __restrict__ tile, uint3
             ncand++;
         }
     };
-    uint32_t b0 = 0;                                                // tiles are padded to a multiple of 4 with never-hit spheres
+    uint32_t b0 = 0;                                                // arrays are padded to a multiple of 4 with never-hit spheres
     for (; b0 + 32 <= cnt; b0 += 32) block(b0, std::integral_constant<uint32_t, 32>());
     for (; b0 < cnt; b0 += 4) block(b0, std::integral_constant<uint32_t, 4>());
     flush();
@@ -313,7 +325,6 @@ __device__ __forceinline__ void scan_tile(const float4* __restrict__ tile, uint3
 __global__ __launch_bounds__(kBlock) void k_mode_r_fast(const float4* __restrict__ tri, const float4* __restrict__ tri_bound,
                                                        const float4* __restrict__ face_rgb, uint32_t n_faces, CamDev cam,
                                                        uint32_t width, uint32_t height, uint32_t* __restrict__ out) {
-    __shared__ float4 tile[kTriTileMax];
     __shared__ uint32_t cand[kCandSlots * kBlock];
     const uint32_t tid = threadIdx.x;
     const uint32_t pixel = blockIdx.x * kBlock + tid;
@@ -330,13 +341,9 @@ __global__ __launch_bounds__(kBlock) void k_mode_r_fast(const float4* __restrict
 
     uint32_t min_i = 0;
     float min_t = __builtin_inff();
-    for (uint32_t t0 = 0; t0 < n_faces; t0 += kTriTileMax) {
-        const uint32_t cnt = min(kTriTileMax, n_faces - t0);
-        __syncthreads();
-        for (uint32_t k = tid; k < kTriTileMax; k += kBlock) tile[k] = k < cnt ? tri_bound[t0 + k] : kPadSphere;
-        __syncthreads();
-        if (!valid) continue;
-        scan_tile<true>(tile, cnt, cand, tid, ox, oy, oz, ux, uy, uz, [&](uint32_t j) {
+    if (valid) {
+        const uint32_t t0 = 0;
+        scan_tile<true>(as_scene(tri_bound), n_faces, cand, tid, ox, oy, oz, ux, uy, uz, [&](uint32_t j) {
             const float4* f = tri + (size_t)(t0 + j) * 4;
             const float4 n = f[0];
             const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);       // SequentialRenderer.cpp:56
@@ -368,18 +375,16 @@ __global__ __launch_bounds__(kBlock) void k_mode_r_fast(const float4* __restrict
 
 // HAS_TRI / HAS_SPH compile the face loop / sphere loop (and the matching shading) in or out, so that a sphere-only
 // scene does not pay registers or code for the triangle path.
-template <bool MULTI_TILE, bool HAS_TRI, bool HAS_SPH>
+// SPH_LDS: the sphere array (<= kSphLdsMax entries) is also copied to LDS once per block, for the per-lane gathers of
+// the exact evaluation (an LDS gather costs ~64 cycles, a global one an L2 round trip per candidate).
+template <bool HAS_TRI, bool HAS_SPH, bool SPH_LDS>
 __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
-    extern __shared__ float4 lds[];
-    uint32_t* cand = reinterpret_cast<uint32_t*>(lds);              // [kCandSlots][kBlock]
-    float4* s_sph = lds + (kCandSlots * kBlock) / 4;
-    float4* s_tri = s_sph + A.sph_tile;
+    __shared__ uint32_t cand[kCandSlots * kBlock];                  // per-lane candidate queues, [slot][thread]
+    extern __shared__ float4 s_sph[];                               // SPH_LDS only
     const uint32_t tid = threadIdx.x, lane = lane_id();
-
-    if (!MULTI_TILE) {                                              // whole scene fits: stage once
-        if (HAS_SPH) for (uint32_t k = tid; k < A.sph_tile; k += kBlock) s_sph[k] = k < A.n_sph ? A.sph[k] : kPadSphere;
-        if (HAS_TRI) for (uint32_t k = tid; k < A.tri_tile; k += kBlock) s_tri[k] = k < A.n_tri ? A.tri_bound[k] : kPadSphere;
-        __syncthreads();
+    if (SPH_LDS) {
+        for (uint32_t k = tid; k < A.n_sph; k += kBlock) s_sph[k] = A.sph[k];
+        __syncthreads();                                            // the only barrier: after it the waves never meet again
     }
 
     Path P;
@@ -413,8 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
             }
             if (item != 0xFFFFFFFFu) { start_path(A, item, P); alive = true; }
         }
-        if (MULTI_TILE) { if (!__syncthreads_or(alive ? 1 : 0)) break; }
-        else            { if (__ballot(alive) == 0ull) break; }
+        if (__ballot(alive) == 0ull) break;                         // waves are independent: no block-level barrier anywhere
         casts += (unsigned long long)__popcll(__ballot(alive));
 
         // ---- nearest hit.  kind: 0 none, 1 triangle, 2 sphere; strict '<' keeps the earlier primitive.
@@ -425,15 +429,10 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
         // Faces: hit_vertex, raytracer_v4.glsl:116-153 (= ray_color's test, SequentialRenderer.cpp:53-98, with the sign of
         // n.o corrected).  The hot loop tests the ray against a slightly inflated bounding sphere of every face; the
         // reference's plane + three-edge test, in its own operation order, runs only for the faces that survive.
-        for (uint32_t t0 = 0; HAS_TRI && t0 < A.n_tri; t0 += A.tri_tile) {
-            const uint32_t cnt = min(A.tri_tile, A.n_tri - t0);
-            if (MULTI_TILE) {
-                __syncthreads();
-                for (uint32_t k = tid; k < A.tri_tile; k += kBlock) s_tri[k] = k < cnt ? A.tri_bound[t0 + k] : kPadSphere;
-                __syncthreads();
-            }
+        if (HAS_TRI) {
+            const uint32_t t0 = 0;
             if (alive) {
-                scan_tile<true>(s_tri, cnt, cand, tid, ox, oy, oz, dx, dy, dz, [&](uint32_t j) {
+                scan_tile<true>(as_scene(A.tri_bound), A.n_tri, cand, tid, ox, oy, oz, dx, dy, dz, [&](uint32_t j) {
                     const float4* f = A.tri + (size_t)(t0 + j) * 4;
                     const float4 n = f[0];
                     const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
@@ -459,16 +458,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
 
         // Analytic spheres: hit_sphere, raytracer_v4.glsl:157-178 with a unit direction.  Exact roots only for the few
         // spheres whose line the ray crosses; the exact candidate rule of DESIGN.md §4.4 is re-checked there.
-        for (uint32_t t0 = 0; HAS_SPH && t0 < A.n_sph; t0 += A.sph_tile) {
-            const uint32_t cnt = min(A.sph_tile, A.n_sph - t0);
-            if (MULTI_TILE) {
-                __syncthreads();
-                for (uint32_t k = tid; k < A.sph_tile; k += kBlock) s_sph[k] = k < cnt ? A.sph[t0 + k] : kPadSphere;
-                __syncthreads();
-            }
+        if (HAS_SPH) {
+            const uint32_t t0 = 0;
             if (alive) {
-                scan_tile<false>(s_sph, cnt, cand, tid, ox, oy, oz, dx, dy, dz, [&](uint32_t j) {
-                    const float4 s = s_sph[j];
+                scan_tile<false>(as_scene(A.sph), A.n_sph, cand, tid, ox, oy, oz, dx, dy, dz, [&](uint32_t j) {
+                    const float4 s = SPH_LDS ? s_sph[j] : A.sph[j];
                     const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
                     const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
                     const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
@@ -851,7 +845,7 @@ int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const f
     if (n_faces != 0 && (!faces || !vertices)) return fail(ctx, RT3_E_ARG, "faces / vertices is NULL");
     RT3_HIP(hipSetDevice(ctx->device));
     // de-index into 4 x float4 per face, in face order (order defines tie-breaking: SequentialRenderer.cpp:71)
-    std::vector<float4> tri((size_t)n_faces * 4), mat(n_faces), bound(n_faces);
+    std::vector<float4> tri((size_t)n_faces * 4), mat(n_faces), bound(((size_t)n_faces + 3) / 4 * 4, kPadSphere);   // scan works in groups of 4
     std::vector<uint32_t> kind(n_faces);
     for (uint32_t i = 0; i < n_faces; i++) {
         const rt3_gface& f = faces[i];
@@ -888,7 +882,7 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
     if (!ctx) return RT3_E_ARG;
     if (n != 0 && (!center_radius || !materials)) return fail(ctx, RT3_E_ARG, "center_radius / materials is NULL");
     RT3_HIP(hipSetDevice(ctx->device));
-    std::vector<float4> sph(n), mat(n);
+    std::vector<float4> sph(((size_t)n + 3) / 4 * 4, kPadSphere), mat(n);                 // scan works in groups of 4
     std::vector<float> invr(n);
     std::vector<uint32_t> kind(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -984,9 +978,6 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     std::memset(&A, 0, sizeof A);
     A.sph = ctx->d_sph; A.sph_invr = ctx->d_sph_invr; A.sph_mat = ctx->d_sph_mat; A.sph_kind = ctx->d_sph_kind; A.n_sph = ctx->n_sph;
     A.tri = ctx->d_tri; A.tri_mat = ctx->d_tri_mat; A.tri_kind = ctx->d_tri_kind; A.tri_bound = ctx->d_tri_bound; A.n_tri = ctx->n_faces;
-    const bool multi = ctx->n_sph > kSphTileMax || ctx->n_faces > kTriTileMax;
-    A.sph_tile = ((std::max(1u, std::min(ctx->n_sph, kSphTileMax)) + 3u) / 4u) * 4u;       // whole 4-sphere mask blocks
-    A.tri_tile = ((std::max(1u, std::min(ctx->n_faces, kTriTileMax)) + 3u) / 4u) * 4u;
     A.cam = cam_dev(cam);
     A.lens_radius = p->lens_radius;
     {
@@ -1013,12 +1004,12 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
         return fail(ctx, RT3_E_DEVICE, "internal: magic-number division self-check failed");
     A.rad = ctx->d_rad; A.work_counter = ctx->d_work; A.cast_counter = ctx->d_casts;
 
-    const size_t lds_bytes = (size_t)kCandSlots * kBlock * 4 + (size_t)A.sph_tile * 16 + (size_t)(ctx->n_faces ? A.tri_tile : 0) * 16;
     using TraceKernel = void (*)(const TraceArgs);
     const bool has_tri = ctx->n_faces > 0, has_sph = ctx->n_sph > 0;
-    TraceKernel kernel = nullptr;
-    if (!multi) kernel = has_tri ? (has_sph ? k_trace<false, true, true> : k_trace<false, true, false>) : k_trace<false, false, true>;
-    else        kernel = has_tri ? (has_sph ? k_trace<true, true, true> : k_trace<true, true, false>) : k_trace<true, false, true>;
+    const bool sph_lds = has_sph && ctx->n_sph <= kSphLdsMax;
+    const size_t lds_bytes = sph_lds ? (size_t)ctx->n_sph * sizeof(float4) : 0;
+    const TraceKernel kernel = has_tri ? (has_sph ? (sph_lds ? k_trace<true, true, true> : k_trace<true, true, false>) : k_trace<true, false, false>)
+                                       : (sph_lds ? k_trace<false, true, true> : k_trace<false, true, false>);
     int per_cu = 0;
     RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes));
     if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_trace does not fit on a CU");
