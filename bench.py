@@ -10,7 +10,7 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the same frame is s
 de-interleaves them on the device.  Total work is fixed, so scaling = "strong".
 
 Prints one JSON line (rank 0) with the metric, a `roofline` object for the dominant kernel (k_trace; bound = FP32
-vector ALU) and a `cpu_baseline` object (the CPU oracle timed on this host's cores on a bounded
+vector ALU; `bound` is "valu" because neither "hbm" nor "mfma" describes this kernel) and a `cpu_baseline` object (the CPU oracle timed on this host's cores on a bounded
 sample of the same workload).
 """
 import argparse
@@ -168,6 +168,16 @@ def main():
         achieved = flop / max(1, launches) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         # algorithmic HBM bytes of the same launch: one 16-B radiance record per sample + the scene once per block
         hbm_bytes = st.samples * 16.0 / max(1, launches)
+        # HBM traffic of one k_trace launch from the committed PMC passes of this same command (FETCH_SIZE is doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is; both are in KiB); null if no profile is present
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench_pmc_k_trace.json")))
+            if world == 1 and (W, H, args.spp, args.depth) == (WIDTH, HEIGHT, SPP, DEPTH):
+                traffic = int((2.0 * pmc["FETCH_SIZE"]["sum_over_dispatches"] / pmc["FETCH_SIZE"]["dispatches"] +
+                               pmc["WRITE_SIZE"]["sum_over_dispatches"] / pmc["WRITE_SIZE"]["dispatches"]) * 1024)
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "Msamples/sec (pixels x spp) at %dx%dx%dspp" % (W, H, args.spp),
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,15 +188,17 @@ def main():
                        "sharding": "interleaved %d-row blocks over %d GPU(s), RCCL gather to rank 0" % (TILE_ROWS, world)},
             "ray_casts": int(agg[1].item()), "prim_tests": int(agg[0].item()),
             "tests_per_s": round(agg[0].item() / (elapsed / args.steps), 1),
-            "roofline": {"bound": "valu", "kernel": "k_trace<false>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "valu", "kernel": "k_trace<false,true,true>", "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
                          "flop_per_test": FLOP_PER_SPHERE_TEST, "kernel_ms": round(k_ms, 3), "launches_per_step": launches,
                          "note": "FP32 vector ALU bound (no MFMA: f32 MFMA peak == f32 VALU peak on gfx950); "
                                  "frac = algorithmic 20 FLOP/test x tests / kernel time / 157.3 TF"},
             "roofline_hbm": {"bound": "hbm", "achieved": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else 0.0,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5) if k_ms > 0 else 0.0,
-                             "note": "algorithmic bytes = 16 B radiance record per sample; the 7.7 KB scene lives in LDS"},
+                             "traffic": traffic,
+                             "note": "algorithmic bytes = 16 B radiance record per sample; the 7.7 KB scene streams through the scalar "
+                                     "cache; traffic = PMC bytes per launch (profiles/), source of truth for re-reads"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(rt3, cr, mats, cam, args.cpu_seconds)
