@@ -119,6 +119,22 @@ int         rt3_set_sample_storage_cap(rt3_ctx* ctx, uint64_t bytes);
 int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces,
                  const float* vertices_xyzw, uint32_t n_vertices,
                  const rt3_material* face_materials);
+/* Incremental form of the same upload, mirroring VulkanRenderer::prerender (VulkanRenderer.cpp:266-399): size the two
+ * device buffers from the entities' pre-declared counts, then fill them entity by entity at running offsets —
+ *   rt3_mesh_put     a CPU-pre-rendered entity; indices are rebased by vertex_offset (transfer_entity, :210-261)
+ *   rt3_mesh_sphere  a sphere tessellated ON THE DEVICE straight into the buffers (gpu_pre_render_sphere,
+ *                    src/lib/entities/Sphere.cpp:355-491; shaders pre_render_sphere_v2_vertices/faces.glsl)
+ * and finally rt3_mesh_commit() de-indexes the merged arrays for the render kernels (face_materials as in rt3_set_mesh).
+ * rt3_mesh_download() copies the merged GFace[] / vec4[] back (the check the author left commented out at
+ * VulkanRenderer.cpp:329-353). */
+int rt3_mesh_begin(rt3_ctx* ctx, uint32_t n_faces, uint32_t n_vertices);
+int rt3_mesh_put(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const float* vertices_xyzw, uint32_t n_vertices,
+                 uint32_t face_offset, uint32_t vertex_offset);
+int rt3_mesh_sphere(rt3_ctx* ctx, const float center[3], float radius, uint32_t n_meridians, uint32_t n_parallels,
+                    const float color[3], uint32_t face_offset, uint32_t vertex_offset);
+int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials);
+int rt3_mesh_download(rt3_ctx* ctx, rt3_gface* faces, float* vertices_xyzw);
+
 /* center_radius: 4 floats per sphere (cx,cy,cz,r), r > 0.  (Sphere{vec3 center; float radius; vec3 color},
  * raytracer_v4.glsl:42-49.) */
 int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material* materials, uint32_t n);

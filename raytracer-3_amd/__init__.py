@@ -70,6 +70,7 @@ EXPORTS = [
     "rt3_transfer_entity", "rt3_camera_update", "rt3_camera_look_at", "rt3_frame_ppm_bytes", "rt3_frame_to_ppm",
     "rt3_scene_three_spheres", "rt3_scene_weekend", "rt3_scene_stress", "rt3_scene_cornell", "rt3_hash_u32",
     "rt3_random_float", "rt3_debug_arith", "rt3_debug_force_plain_mode_r",
+    "rt3_mesh_begin", "rt3_mesh_put", "rt3_mesh_sphere", "rt3_mesh_commit", "rt3_mesh_download",
 ]
 
 _lib = None
@@ -112,6 +113,9 @@ def lib():
         "rt3_hash_u32": (u32, [u32]), "rt3_random_float": (f32, [u32]),
         "rt3_debug_arith": (i32, [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]),
         "rt3_debug_force_plain_mode_r": (i32, [vp, i32]),
+        "rt3_mesh_begin": (i32, [vp, u32, u32]), "rt3_mesh_put": (i32, [vp, vp, u32, vp, u32, u32, u32]),
+        "rt3_mesh_sphere": (i32, [vp, vp, f32, u32, u32, vp, u32, u32]), "rt3_mesh_commit": (i32, [vp, vp]),
+        "rt3_mesh_download": (i32, [vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -264,6 +268,7 @@ def create_sphere(center, radius, n_meridians, n_parallels, color, material=None
         e.type = et_analytic_sphere
         return e
     e.type, e.pre_render_operation = et_sphere, epro_generate_sphere
+    e.pre_render_mode = eprmf_cpu | eprmf_gpu          # Sphere.cpp:94-98: spheres can also be tessellated on the GPU
     e.pre_render_faces = lib().rt3_sphere_face_count(n_meridians, n_parallels)
     e.pre_render_vertices = lib().rt3_sphere_vertex_count(n_meridians, n_parallels)
     return e
@@ -398,6 +403,7 @@ class HipRenderer(Renderer):
         self._path = None            # rt3_params template when Mode X is requested
         self.n_faces = 0
         self.n_spheres = 0
+        self._mesh_counts = (0, 0)
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -415,34 +421,63 @@ class HipRenderer(Renderer):
             raise Fatal(lib().rt3_last_error(self._ctx).decode())
 
     # -- scene ---------------------------------------------------------------------------------------
-    def prerender(self, entities):
-        """Renderer::prerender: flatten the entities (order = array order) and upload.  Replaces the old scene."""
-        parts, part_mats, spheres, smats = [], [], [], []
-        any_mat = False
+    def prerender(self, entities, gpu_prerender=False):
+        """Renderer::prerender: flatten the entities (order = array order) into the device buffers.  Replaces the old
+        scene.  With gpu_prerender, entities flagged eprmf_gpu (tessellated spheres, as in the reference's Vulkan build)
+        are generated on the device at their running offsets (VulkanRenderer.cpp:305-327); everything else is
+        pre-rendered on the host and transferred (VulkanRenderer.cpp:355-387)."""
+        mesh_ents, spheres, smats = [], [], []
         for i, e in enumerate(entities):
             if e.type == et_analytic_sphere:
                 spheres.append((e.center[0], e.center[1], e.center[2], e.radius))
                 smats.append(e.material if e.material is not None else _material(MAT_FLAT, e.color))
-                continue
-            if not (e.pre_render_mode & eprmf_cpu):
+            elif not (e.pre_render_mode & (eprmf_cpu | eprmf_gpu)):
                 raise Fatal("Entity %d cannot be pre-rendered by this back-end." % i)
-            f, v = pre_render_entity(e)
-            parts.append((f, v))
-            if e.material is not None:
-                any_mat = True
-                part_mats.append(np.repeat(e.material, len(f)))
             else:
-                m = np.zeros(len(f), MATERIAL)
-                m["rgb"] = f["color"]
-                m["kind"] = MAT_FLAT
-                part_mats.append(m)
-        faces, verts = merge_entities(parts) if parts else (np.zeros(0, GFACE), np.zeros((0, 4), np.float32))
-        fmats = np.concatenate(part_mats) if (parts and any_mat) else None
-        self.set_mesh(faces, verts, fmats)
+                mesh_ents.append(e)
+        nf = sum(e.pre_render_faces for e in mesh_ents)
+        nv = sum(e.pre_render_vertices for e in mesh_ents)
+        any_mat = any(e.material is not None for e in mesh_ents)
+        self._check(lib().rt3_mesh_begin(self._ctx, nf, nv))
+        fo = vo = 0
+        part_mats = []
+        for e in mesh_ents:
+            if gpu_prerender and (e.pre_render_mode & eprmf_gpu) and e.pre_render_operation == epro_generate_sphere:
+                self._check(lib().rt3_mesh_sphere(self._ctx, _f3(e.center), np.float32(e.radius), e.n_meridians, e.n_parallels,
+                                                  _f3(e.color), fo, vo))
+                colors = None
+            else:
+                f, v = pre_render_entity(e)
+                self._check(lib().rt3_mesh_put(self._ctx, _p(f), len(f), _p(v), len(v), fo, vo))
+                colors = f["color"]
+            if any_mat:
+                if e.material is not None:
+                    part_mats.append(np.repeat(e.material, e.pre_render_faces))
+                else:
+                    if colors is None:
+                        raise Fatal("a device-tessellated sphere needs a material when other entities have one")
+                    m = np.zeros(e.pre_render_faces, MATERIAL)
+                    m["rgb"] = colors
+                    m["kind"] = MAT_FLAT
+                    part_mats.append(m)
+            fo += e.pre_render_faces
+            vo += e.pre_render_vertices
+        fmats = np.ascontiguousarray(np.concatenate(part_mats)) if (mesh_ents and any_mat) else None
+        self._check(lib().rt3_mesh_commit(self._ctx, _p(fmats)))
+        self.n_faces = nf
+        self._mesh_counts = (nf, nv)
         if spheres:
             self.set_spheres(np.array(spheres, np.float32), np.concatenate(smats))
         else:
             self.set_spheres(np.zeros((0, 4), np.float32), np.zeros(0, MATERIAL))
+
+    def mesh_download(self):
+        """The merged GFace[] / vec4[] as they sit on the device (after prerender / set_mesh)."""
+        nf, nv = getattr(self, "_mesh_counts", (0, 0))
+        faces = np.zeros(nf, GFACE)
+        verts = np.zeros((nv, 4), np.float32)
+        self._check(lib().rt3_mesh_download(self._ctx, _p(faces), _p(verts)))
+        return faces, verts
 
     def set_mesh(self, faces, verts, face_materials=None):
         faces = np.ascontiguousarray(faces)
@@ -453,6 +488,7 @@ class HipRenderer(Renderer):
             assert face_materials.dtype == MATERIAL and len(face_materials) == len(faces)
         self._check(lib().rt3_set_mesh(self._ctx, _p(faces), len(faces), _p(verts), len(verts), _p(face_materials)))
         self.n_faces = len(faces)
+        self._mesh_counts = (len(faces), len(verts))
 
     def set_spheres(self, center_radius, materials):
         cr = np.ascontiguousarray(center_radius, np.float32).reshape(-1, 4)

@@ -611,6 +611,99 @@ __global__ void k_debug_arith(const float* a, const float* b, uint32_t n, float*
     pk[i] = pack_pixel(a[i], b[i], u);
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Device-side scene assembly: HIP equivalents of the reference's pre-render shaders and of the merge
+// ------------------------------------------------------------------------------------------------------
+struct SphereGen { float cx, cy, cz, radius; uint32_t m, p; float r, g, b; uint32_t face_offset, vertex_offset; };
+
+// compute_point (Sphere.cpp:69-79 / pre_render_sphere_v2_vertices.glsl:77-83).  The CPU form is followed (double
+// trig on a float ratio, rounded to float per component), not the shader's float trig, so that a device-tessellated
+// sphere equals a host-tessellated one.
+__device__ __forceinline__ float4 sphere_point(const SphereGen& s, float fx, float fy) {
+    const double ty = M_PI * (double)(fy / (float)(s.p - 1));
+    const double tx = 2 * M_PI * (double)(fx / (float)s.m);
+    const float ux = (float)(sin(ty) * cos(tx)), uy = (float)cos(ty), uz = (float)(sin(ty) * sin(tx));
+    return make_float4(s.cx + s.radius * ux, s.cy + s.radius * uy, s.cz + s.radius * uz, 0.0f);
+}
+
+// pre_render_sphere_v2_vertices.glsl:88-113: one thread per (meridian x, parallel y)
+__global__ void k_prerender_sphere_vertices(SphereGen s, float4* __restrict__ verts) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x == 0 && y == 0) verts[s.vertex_offset] = sphere_point(s, 0.0f, 0.0f);
+    else if (x < s.m && y > 0 && y < s.p - 1) verts[s.vertex_offset + 1 + (y - 1) * s.m + x] = sphere_point(s, (float)x, (float)y);
+    else if (x == 0 && y == s.p - 1) verts[s.vertex_offset + 1 + (y - 1) * s.m] = sphere_point(s, 0.0f, (float)y);
+}
+
+__device__ __forceinline__ void store_face(rt3_gface* f, uint32_t a, uint32_t b, uint32_t c, float4 pa, float4 pb, float4 pc,
+                                           const SphereGen& s) {
+    // normal = normalize(cross(c - a, b - a)) with glm's evaluation order; colour = colour * |n . (0,0,-1)| (Sphere.cpp:153-155)
+    const float ex = pc.x - pa.x, ey = pc.y - pa.y, ez = pc.z - pa.z, fx = pb.x - pa.x, fy = pb.y - pa.y, fz = pb.z - pa.z;
+    const float nx = ey * fz - fy * ez, ny = ez * fx - fz * ex, nz = ex * fy - fx * ey;
+    const float inv = 1.0f / __builtin_sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+    const float ux = nx * inv, uy = ny * inv, uz = nz * inv;
+    const float shade = __builtin_fabsf(ux * 0.0f + uy * 0.0f + uz * -1.0f);
+    f->v1 = a; f->v2 = b; f->v3 = c; f->_pad0 = 0;
+    f->normal[0] = ux; f->normal[1] = uy; f->normal[2] = uz; f->_pad1 = 0;
+    f->color[0] = s.r * shade; f->color[1] = s.g * shade; f->color[2] = s.b * shade; f->_pad2 = 0;
+}
+
+// pre_render_sphere_v2_faces.glsl:83-194: one thread per (x, y >= 1); reads the vertices the first kernel wrote
+__global__ void k_prerender_sphere_faces(SphereGen s, rt3_gface* __restrict__ faces, const float4* __restrict__ verts) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    if (x >= s.m || y >= s.p) return;
+    const uint32_t xm1 = x > 0 ? x - 1 : s.m - 1, vo = s.vertex_offset;
+    rt3_gface* out = faces + s.face_offset;
+    if (y == 1) {
+        const uint32_t a = vo, b = vo + 1 + xm1, c = vo + 1 + x;
+        store_face(out + x, a, b, c, verts[a], verts[b], verts[c], s);
+    } else if (y < s.p - 1) {
+        const uint32_t base = s.m + 2 * (y - 2) * s.m;
+        const uint32_t p1 = vo + 1 + (y - 2) * s.m + xm1, p2 = vo + 1 + (y - 2) * s.m + x;
+        const uint32_t p3 = vo + 1 + (y - 1) * s.m + xm1, p4 = vo + 1 + (y - 1) * s.m + x;
+        store_face(out + base + 2 * x, p1, p3, p4, verts[p1], verts[p3], verts[p4], s);
+        store_face(out + base + 2 * x + 1, p1, p2, p4, verts[p1], verts[p2], verts[p4], s);
+    } else {
+        const uint32_t base = s.m + 2 * (y - 2) * s.m;
+        const uint32_t a = vo + 1 + (y - 1) * s.m, b = vo + 1 + (y - 2) * s.m + xm1, c = vo + 1 + (y - 2) * s.m + x;
+        store_face(out + base + x, a, b, c, verts[a], verts[b], verts[c], s);
+    }
+}
+
+// De-indexes the merged GFace[] / vec4[] into what the render kernels read: 4 float4 per face (n + plane distance, p1, p2,
+// p3), the bounding sphere of §5.1, the material.  Entries [n_faces, n_pad) of `bound` become never-hit records.
+__global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4* __restrict__ verts, uint32_t n_faces, uint32_t n_pad,
+                              uint32_t n_verts, const rt3_material* __restrict__ mats, float4* __restrict__ tri, float4* __restrict__ bound,
+                              float4* __restrict__ mat, uint32_t* __restrict__ kind, uint32_t* __restrict__ error_flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    if (i >= n_faces) { bound[i] = kPadSphere; return; }
+    const rt3_gface f = faces[i];
+    if (f.v1 >= n_verts || f.v2 >= n_verts || f.v3 >= n_verts) { atomicOr(error_flag, 1u); bound[i] = kPadSphere; return; }
+    const float4 p1 = verts[f.v1], p2 = verts[f.v2], p3 = verts[f.v3];
+    tri[4 * (size_t)i] = make_float4(f.normal[0], f.normal[1], f.normal[2], dot3(f.normal[0], f.normal[1], f.normal[2], p1.x, p1.y, p1.z));
+    tri[4 * (size_t)i + 1] = make_float4(p1.x, p1.y, p1.z, 0.0f);
+    tri[4 * (size_t)i + 2] = make_float4(p2.x, p2.y, p2.z, 0.0f);
+    tri[4 * (size_t)i + 3] = make_float4(p3.x, p3.y, p3.z, 0.0f);
+    // bounding sphere: centroid + largest vertex distance in double, inflated (0.1 % + 1e-5 * (1 + max |coordinate|)), r^2 rounded up
+    const double cx = ((double)p1.x + p2.x + p3.x) / 3.0, cy = ((double)p1.y + p2.y + p3.y) / 3.0, cz = ((double)p1.z + p2.z + p3.z) / 3.0;
+    double r2 = 0.0, big = 0.0;
+    const float4 ps[3] = { p1, p2, p3 };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double ddx = ps[k].x - cx, ddy = ps[k].y - cy, ddz = ps[k].z - cz;
+        r2 = fmax(r2, ddx * ddx + ddy * ddy + ddz * ddz);
+        big = fmax(big, fmax(fabs((double)ps[k].x), fmax(fabs((double)ps[k].y), fabs((double)ps[k].z))));
+    }
+    const double r = sqrt(r2) * 1.001 + 1e-5 * (1.0 + big);
+    float r2f = (float)(r * r);
+    if ((double)r2f < r * r) r2f = __uint_as_float(__float_as_uint(r2f) + 1u);
+    if (!(r2f >= 0.0f)) r2f = __builtin_inff();                    // NaN / inf vertices: always a candidate, the exact test decides
+    bound[i] = make_float4((float)cx, (float)cy, (float)cz, r2f);
+    if (mats) { const rt3_material m = mats[i]; mat[i] = make_float4(m.rgb[0], m.rgb[1], m.rgb[2], m.param); kind[i] = m.kind; }
+    else { mat[i] = make_float4(f.color[0], f.color[1], f.color[2], 0.0f); kind[i] = RT3_MAT_FLAT; }
+}
+
 }  // namespace
 
 // ======================================================================================================
@@ -625,6 +718,9 @@ struct rt3_ctx {
     // mesh
     uint32_t n_faces = 0;
     float4* d_tri = nullptr; float4* d_tri_mat = nullptr; uint32_t* d_tri_kind = nullptr; float4* d_tri_bound = nullptr;
+    // merged entity buffers on the device (GFace[] / vec4[] as the reference keeps them), filled by rt3_mesh_*
+    rt3_gface* d_gfaces = nullptr; float4* d_verts = nullptr; uint32_t cap_gfaces = 0, cap_verts = 0;
+    rt3_material* d_face_mats_in = nullptr; uint32_t* d_error = nullptr;
     // spheres
     uint32_t n_sph = 0;
     float4* d_sph = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
@@ -738,24 +834,6 @@ bool fastdiv_ok(uint32_t d, uint32_t n_max) {
     return true;
 }
 
-// Bounding sphere of a face for the hot loop: centroid + largest vertex distance (double), inflated by 0.1 % plus an
-// absolute term that scales with the coordinates, so that neither the rounding of the centre to float nor the float
-// noise of the exact plane/edge test can place an accepted hit outside it.  r^2 is rounded up.
-float4 face_bound(const float* p1, const float* p2, const float* p3) {
-    const double cx = ((double)p1[0] + p2[0] + p3[0]) / 3.0, cy = ((double)p1[1] + p2[1] + p3[1]) / 3.0, cz = ((double)p1[2] + p2[2] + p3[2]) / 3.0;
-    double r2 = 0.0, big = 0.0;
-    for (const float* p : { p1, p2, p3 }) {
-        const double ddx = p[0] - cx, ddy = p[1] - cy, ddz = p[2] - cz;
-        r2 = std::max(r2, ddx * ddx + ddy * ddy + ddz * ddz);
-        big = std::max(big, std::max(std::fabs((double)p[0]), std::max(std::fabs((double)p[1]), std::fabs((double)p[2]))));
-    }
-    const double r = std::sqrt(r2) * 1.001 + 1e-5 * (1.0 + big);
-    float r2f = (float)(r * r);
-    if ((double)r2f < r * r) r2f = std::nextafter(r2f, INFINITY);
-    if (!(r2f >= 0.0f)) r2f = INFINITY;                             // NaN / inf vertices: always a candidate, the exact test decides
-    return make_float4((float)cx, (float)cy, (float)cz, r2f);
-}
-
 bool row_owned(const rt3_params* p, uint32_t y) {
     if (p->tile_count <= 1) return true;
     return ((y / p->tile_rows) % p->tile_count) == p->tile_index;
@@ -814,7 +892,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = { ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_sph, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
+    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_sph, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_out, ctx->d_work, ctx->d_casts };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -839,43 +917,102 @@ int rt3_debug_force_plain_mode_r(rt3_ctx* ctx, int on) {
     return 0;
 }
 
+int rt3_mesh_begin(rt3_ctx* ctx, uint32_t n_faces, uint32_t n_vertices) {
+    if (!ctx) return RT3_E_ARG;
+    RT3_HIP(hipSetDevice(ctx->device));
+    if (ctx->d_gfaces) { RT3_HIP(hipFree(ctx->d_gfaces)); ctx->d_gfaces = nullptr; }
+    if (ctx->d_verts) { RT3_HIP(hipFree(ctx->d_verts)); ctx->d_verts = nullptr; }
+    if (n_faces) RT3_HIP(hipMalloc((void**)&ctx->d_gfaces, (size_t)n_faces * sizeof(rt3_gface)));
+    if (n_vertices) RT3_HIP(hipMalloc((void**)&ctx->d_verts, (size_t)n_vertices * sizeof(float4)));
+    if (n_faces) RT3_HIP(hipMemsetAsync(ctx->d_gfaces, 0, (size_t)n_faces * sizeof(rt3_gface), ctx->stream));
+    if (n_vertices) RT3_HIP(hipMemsetAsync(ctx->d_verts, 0, (size_t)n_vertices * sizeof(float4), ctx->stream));
+    ctx->cap_gfaces = n_faces;
+    ctx->cap_verts = n_vertices;
+    return 0;
+}
+
+int rt3_mesh_put(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const float* vertices, uint32_t n_vertices,
+                 uint32_t face_offset, uint32_t vertex_offset) {
+    if (!ctx) return RT3_E_ARG;
+    if ((n_faces && !faces) || (n_vertices && !vertices)) return fail(ctx, RT3_E_ARG, "faces / vertices is NULL");
+    if ((uint64_t)face_offset + n_faces > ctx->cap_gfaces || (uint64_t)vertex_offset + n_vertices > ctx->cap_verts)
+        return fail(ctx, RT3_E_ARG, "rt3_mesh_put: entity does not fit in the buffers sized by rt3_mesh_begin");
+    RT3_HIP(hipSetDevice(ctx->device));
+    std::vector<rt3_gface> rebased(faces, faces + n_faces);         // transfer_entity: indices += running vertex count
+    for (rt3_gface& f : rebased) { f.v1 += vertex_offset; f.v2 += vertex_offset; f.v3 += vertex_offset; }
+    if (n_faces) RT3_HIP(hipMemcpyAsync(ctx->d_gfaces + face_offset, rebased.data(), (size_t)n_faces * sizeof(rt3_gface), hipMemcpyHostToDevice, ctx->stream));
+    if (n_vertices) RT3_HIP(hipMemcpyAsync(ctx->d_verts + vertex_offset, vertices, (size_t)n_vertices * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    RT3_HIP(hipStreamSynchronize(ctx->stream));                     // `rebased` is a temporary
+    return 0;
+}
+
+int rt3_mesh_sphere(rt3_ctx* ctx, const float center[3], float radius, uint32_t n_meridians, uint32_t n_parallels, const float color[3],
+                    uint32_t face_offset, uint32_t vertex_offset) {
+    if (!ctx) return RT3_E_ARG;
+    if (!center || !color || n_meridians < 3 || n_parallels < 3) return fail(ctx, RT3_E_ARG, "rt3_mesh_sphere: need >= 3 meridians and parallels");
+    const uint32_t nf = 2 * n_meridians * (n_parallels - 2), nv = 2 + (n_parallels - 2) * n_meridians;
+    if ((uint64_t)face_offset + nf > ctx->cap_gfaces || (uint64_t)vertex_offset + nv > ctx->cap_verts)
+        return fail(ctx, RT3_E_ARG, "rt3_mesh_sphere: entity does not fit in the buffers sized by rt3_mesh_begin");
+    RT3_HIP(hipSetDevice(ctx->device));
+    const SphereGen g{ center[0], center[1], center[2], radius, n_meridians, n_parallels, color[0], color[1], color[2], face_offset, vertex_offset };
+    const dim3 blk(32, 8);
+    hipLaunchKernelGGL(k_prerender_sphere_vertices, dim3((n_meridians + 31) / 32, (n_parallels + 7) / 8), blk, 0, ctx->stream, g, ctx->d_verts);
+    RT3_HIP(hipGetLastError());
+    // same stream: the faces kernel starts after the vertices are written (the barrier of Sphere.cpp:446-450)
+    hipLaunchKernelGGL(k_prerender_sphere_faces, dim3((n_meridians + 31) / 32, (n_parallels - 1 + 7) / 8), blk, 0, ctx->stream, g, ctx->d_gfaces, ctx->d_verts);
+    RT3_HIP(hipGetLastError());
+    return 0;
+}
+
+int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
+    if (!ctx) return RT3_E_ARG;
+    RT3_HIP(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
+    for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_face_mats_in })
+        if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
+    ctx->n_faces = 0;
+    if (n == 0) return 0;
+    if (face_materials)
+        for (uint32_t i = 0; i < n; i++)
+            if (face_materials[i].kind > RT3_MAT_DIELECTRIC) return fail(ctx, RT3_E_ARG, "unknown material kind");
+    if (!ctx->d_error) RT3_HIP(hipMalloc((void**)&ctx->d_error, 4));
+    RT3_HIP(hipMemsetAsync(ctx->d_error, 0, 4, ctx->stream));
+    RT3_HIP(hipMalloc((void**)&ctx->d_tri, (size_t)n * 4 * sizeof(float4)));
+    RT3_HIP(hipMalloc((void**)&ctx->d_tri_mat, (size_t)n * sizeof(float4)));
+    RT3_HIP(hipMalloc((void**)&ctx->d_tri_kind, (size_t)n * sizeof(uint32_t)));
+    RT3_HIP(hipMalloc((void**)&ctx->d_tri_bound, (size_t)n_pad * sizeof(float4)));
+    if (face_materials) {
+        RT3_HIP(hipMalloc((void**)&ctx->d_face_mats_in, (size_t)n * sizeof(rt3_material)));
+        RT3_HIP(hipMemcpyAsync(ctx->d_face_mats_in, face_materials, (size_t)n * sizeof(rt3_material), hipMemcpyHostToDevice, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_commit_mesh, dim3((n_pad + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, ctx->d_gfaces, ctx->d_verts, n, n_pad,
+                       ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error);
+    RT3_HIP(hipGetLastError());
+    uint32_t err = 0;
+    RT3_HIP(hipMemcpyAsync(&err, ctx->d_error, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    if (err) return fail(ctx, RT3_E_ARG, "a face references a vertex out of range");
+    ctx->n_faces = n;
+    return 0;
+}
+
+int rt3_mesh_download(rt3_ctx* ctx, rt3_gface* faces, float* vertices) {
+    if (!ctx) return RT3_E_ARG;
+    RT3_HIP(hipSetDevice(ctx->device));
+    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    if (faces && ctx->cap_gfaces) RT3_HIP(hipMemcpy(faces, ctx->d_gfaces, (size_t)ctx->cap_gfaces * sizeof(rt3_gface), hipMemcpyDeviceToHost));
+    if (vertices && ctx->cap_verts) RT3_HIP(hipMemcpy(vertices, ctx->d_verts, (size_t)ctx->cap_verts * sizeof(float4), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int rt3_set_mesh(rt3_ctx* ctx, const rt3_gface* faces, uint32_t n_faces, const float* vertices, uint32_t n_vertices,
                  const rt3_material* face_materials) {
     if (!ctx) return RT3_E_ARG;
     if (n_faces != 0 && (!faces || !vertices)) return fail(ctx, RT3_E_ARG, "faces / vertices is NULL");
-    RT3_HIP(hipSetDevice(ctx->device));
-    // de-index into 4 x float4 per face, in face order (order defines tie-breaking: SequentialRenderer.cpp:71)
-    std::vector<float4> tri((size_t)n_faces * 4), mat(n_faces), bound(((size_t)n_faces + 3) / 4 * 4, kPadSphere);   // scan works in groups of 4
-    std::vector<uint32_t> kind(n_faces);
-    for (uint32_t i = 0; i < n_faces; i++) {
-        const rt3_gface& f = faces[i];
-        if (f.v1 >= n_vertices || f.v2 >= n_vertices || f.v3 >= n_vertices)
-            return fail(ctx, RT3_E_ARG, "face " + std::to_string(i) + " references a vertex out of range");
-        const float* p1 = vertices + 4 * (size_t)f.v1;
-        const float* p2 = vertices + 4 * (size_t)f.v2;
-        const float* p3 = vertices + 4 * (size_t)f.v3;
-        const float pd = f.normal[0] * p1[0] + f.normal[1] * p1[1] + f.normal[2] * p1[2];     // dot3(normal, p1), :67
-        tri[4 * (size_t)i] = make_float4(f.normal[0], f.normal[1], f.normal[2], pd);
-        tri[4 * (size_t)i + 1] = make_float4(p1[0], p1[1], p1[2], 0.0f);
-        tri[4 * (size_t)i + 2] = make_float4(p2[0], p2[1], p2[2], 0.0f);
-        tri[4 * (size_t)i + 3] = make_float4(p3[0], p3[1], p3[2], 0.0f);
-        bound[i] = face_bound(p1, p2, p3);
-        if (face_materials) {
-            const rt3_material& m = face_materials[i];
-            if (m.kind > RT3_MAT_DIELECTRIC) return fail(ctx, RT3_E_ARG, "unknown material kind");
-            mat[i] = make_float4(m.rgb[0], m.rgb[1], m.rgb[2], m.param);
-            kind[i] = m.kind;
-        } else {
-            mat[i] = make_float4(f.color[0], f.color[1], f.color[2], 0.0f);
-            kind[i] = RT3_MAT_FLAT;
-        }
-    }
     int rc;
-    if ((rc = upload(ctx, &ctx->d_tri, tri)) || (rc = upload(ctx, &ctx->d_tri_mat, mat)) || (rc = upload(ctx, &ctx->d_tri_kind, kind)) ||
-        (rc = upload(ctx, &ctx->d_tri_bound, bound)))
-        return rc;
-    ctx->n_faces = n_faces;
-    return 0;
+    if ((rc = rt3_mesh_begin(ctx, n_faces, n_vertices))) return rc;
+    if ((rc = rt3_mesh_put(ctx, faces, n_faces, vertices, n_vertices, 0, 0))) return rc;
+    return rt3_mesh_commit(ctx, face_materials);
 }
 
 int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material* materials, uint32_t n) {

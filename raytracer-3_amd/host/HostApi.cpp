@@ -115,7 +115,7 @@ Sphere* ECS::create_sphere(const glm::vec3& center, float radius, uint32_t n_mer
     Sphere* s = new Sphere;
     s->center = center; s->radius = radius; s->n_meridians = n_meridians; s->n_parallels = n_parallels; s->color = color;
     if (n_meridians == 0 && n_parallels == 0) { s->type = et_analytic_sphere; return s; }
-    s->type = et_sphere; s->pre_render_mode = eprmf_cpu; s->pre_render_operation = epro_generate_sphere;
+    s->type = et_sphere; s->pre_render_mode = eprmf_cpu | eprmf_gpu; s->pre_render_operation = epro_generate_sphere;   // Sphere.cpp:94-98
     s->pre_render_faces = rt3_sphere_face_count(n_meridians, n_parallels);
     s->pre_render_vertices = rt3_sphere_vertex_count(n_meridians, n_parallels);
     return s;
@@ -157,18 +157,22 @@ HipRenderer::HipRenderer(const std::vector<int>& devices) {
 HipRenderer::~HipRenderer() { for (rt3_ctx* c : ctx) rt3_destroy(c); }
 
 void HipRenderer::prerender(const Tools::Array<RenderEntity*>& entities) {
-    // size the merged buffers from the counts every entity declares up front (RenderEntity.hpp:84-88)
-    size_t total_f = 0, total_v = 0;
+    // VulkanRenderer::prerender's shape (VulkanRenderer.cpp:266-399): size the device buffers from the counts every entity
+    // declares up front (RenderEntity.hpp:84-88), then fill them entity by entity at running offsets — tessellated on the
+    // device when the entity allows it and gpu_prerender is on (:305-327), else pre-rendered here and transferred (:355-387).
+    uint32_t total_f = 0, total_v = 0;
     bool any_material = false;
     for (size_t i = 0; i < entities.size(); i++) {
         if (entities[i]->type == et_analytic_sphere) continue;
         total_f += entities[i]->pre_render_faces; total_v += entities[i]->pre_render_vertices;
         any_material = any_material || entities[i]->has_material;
     }
-    std::vector<rt3_gface> faces(total_f), tmp_f;
-    std::vector<float> verts(4 * total_v), tmp_v, sph;
+    for (rt3_ctx* c : ctx) if (rt3_mesh_begin(c, total_f, total_v) != 0) throw Fatal(rt3_last_error(c));
+
+    std::vector<rt3_gface> tmp_f;
+    std::vector<float> tmp_v, sph;
     std::vector<rt3_material> face_mats, sph_mats;
-    uint32_t nf = 0, nv = 0;
+    uint32_t fo = 0, vo = 0;
     for (size_t i = 0; i < entities.size(); i++) {
         RenderEntity* e = entities[i];
         if (e->type == et_analytic_sphere) {
@@ -177,42 +181,54 @@ void HipRenderer::prerender(const Tools::Array<RenderEntity*>& entities) {
             sph_mats.push_back(e->has_material ? e->material : emissive(s->color));
             continue;
         }
-        if (!(e->pre_render_mode & eprmf_cpu))
-            throw Fatal("Entity " + std::to_string(i) + " of type " + entity_type_names[e->type] + " cannot be pre-rendered by this back-end.");
-        tmp_f.assign(e->pre_render_faces, rt3_gface{});
-        tmp_v.assign(4 * (size_t)e->pre_render_vertices, 0.0f);
-        switch (e->pre_render_operation) {
-            case epro_generate_triangle: {
-                const Triangle* t = static_cast<const Triangle*>(e);
-                rt3_prerender_triangle(t->points[0].ptr(), t->points[1].ptr(), t->points[2].ptr(), t->color.ptr(), tmp_f.data(), tmp_v.data());
-                break;
+        const bool on_device = gpu_prerender && (e->pre_render_mode & eprmf_gpu) && e->pre_render_operation == epro_generate_sphere &&
+                               (!any_material || e->has_material);
+        if (on_device) {
+            const Sphere* s = static_cast<const Sphere*>(e);
+            for (rt3_ctx* c : ctx)
+                if (rt3_mesh_sphere(c, s->center.ptr(), s->radius, s->n_meridians, s->n_parallels, s->color.ptr(), fo, vo) != 0) throw Fatal(rt3_last_error(c));
+        } else {
+            if (!(e->pre_render_mode & eprmf_cpu))
+                throw Fatal("Entity " + std::to_string(i) + " of type " + entity_type_names[e->type] + " cannot be pre-rendered by this back-end.");
+            tmp_f.assign(e->pre_render_faces, rt3_gface{});
+            tmp_v.assign(4 * (size_t)e->pre_render_vertices, 0.0f);
+            switch (e->pre_render_operation) {
+                case epro_generate_triangle: {
+                    const Triangle* t = static_cast<const Triangle*>(e);
+                    rt3_prerender_triangle(t->points[0].ptr(), t->points[1].ptr(), t->points[2].ptr(), t->color.ptr(), tmp_f.data(), tmp_v.data());
+                    break;
+                }
+                case epro_generate_sphere: {
+                    const Sphere* s = static_cast<const Sphere*>(e);
+                    rt3_prerender_sphere(s->center.ptr(), s->radius, s->n_meridians, s->n_parallels, s->color.ptr(), tmp_f.data(), tmp_v.data());
+                    break;
+                }
+                case epro_load_object_file: {
+                    const Object* o = static_cast<const Object*>(e);
+                    if (rt3_prerender_object(o->file_path.c_str(), o->center.ptr(), o->scale, o->color.ptr(), tmp_f.data(),
+                                             e->pre_render_faces, tmp_v.data(), e->pre_render_vertices) != 0)
+                        throw Fatal("Could not load object file '" + o->file_path + "'");
+                    break;
+                }
+                default:
+                    throw Fatal("Entity " + std::to_string(i) + " wants to be pre-rendered using unsupported operation '" +
+                                entity_pre_render_operation_names[e->pre_render_operation] + "'.");
             }
-            case epro_generate_sphere: {
-                const Sphere* s = static_cast<const Sphere*>(e);
-                rt3_prerender_sphere(s->center.ptr(), s->radius, s->n_meridians, s->n_parallels, s->color.ptr(), tmp_f.data(), tmp_v.data());
-                break;
-            }
-            case epro_load_object_file: {
-                const Object* o = static_cast<const Object*>(e);
-                if (rt3_prerender_object(o->file_path.c_str(), o->center.ptr(), o->scale, o->color.ptr(), tmp_f.data(),
-                                         e->pre_render_faces, tmp_v.data(), e->pre_render_vertices) != 0)
-                    throw Fatal("Could not load object file '" + o->file_path + "'");
-                break;
-            }
-            default:
-                throw Fatal("Entity " + std::to_string(i) + " wants to be pre-rendered using unsupported operation '" +
-                            entity_pre_render_operation_names[e->pre_render_operation] + "'.");
+            for (rt3_ctx* c : ctx)
+                if (rt3_mesh_put(c, tmp_f.data(), e->pre_render_faces, tmp_v.data(), e->pre_render_vertices, fo, vo) != 0) throw Fatal(rt3_last_error(c));
         }
         if (any_material)
-            for (const rt3_gface& f : tmp_f)
-                face_mats.push_back(e->has_material ? e->material : emissive(glm::vec3(f.color[0], f.color[1], f.color[2])));
-        rt3_transfer_entity(faces.data(), &nf, verts.data(), &nv, tmp_f.data(), e->pre_render_faces, tmp_v.data(), e->pre_render_vertices);
+            for (uint32_t k = 0; k < e->pre_render_faces; k++)
+                face_mats.push_back(e->has_material ? e->material
+                                                    : emissive(glm::vec3(tmp_f[k].color[0], tmp_f[k].color[1], tmp_f[k].color[2])));
+        fo += e->pre_render_faces;
+        vo += e->pre_render_vertices;
     }
     for (rt3_ctx* c : ctx) {
-        if (rt3_set_mesh(c, faces.data(), nf, verts.data(), nv, any_material ? face_mats.data() : nullptr) != 0) throw Fatal(rt3_last_error(c));
+        if (rt3_mesh_commit(c, any_material ? face_mats.data() : nullptr) != 0) throw Fatal(rt3_last_error(c));
         if (rt3_set_spheres(c, sph.data(), sph_mats.data(), (uint32_t)sph_mats.size()) != 0) throw Fatal(rt3_last_error(c));
     }
-    n_faces = nf;
+    n_faces = fo;
     n_spheres = sph_mats.size();
 }
 

@@ -25,6 +25,7 @@ struct Options {
     uint32_t width = 800, height = 600;
     std::string scene = "builtin";
     uint32_t spp = 0, depth = 50, seed = 1, gpus = 1;
+    bool gpu_prerender = false;
 };
 
 void print_usage(const char* exe) {
@@ -38,6 +39,7 @@ void print_usage(const char* exe) {
               << "\t   --depth\tMaximum ray casts per path (default: 50).\n"
               << "\t   --seed\tRender seed (default: 1).\n"
               << "\t   --gpus\tNumber of GPUs to shard the frame over (default: 1).\n"
+              << "\t   --gpu-prerender\tTessellate spheres on the GPU instead of the host (same arrays).\n"
               << "\n\t-h,--help\tShows this help menu, then exits.\n\n";
 }
 
@@ -72,6 +74,7 @@ int parse_cli(Options& opt, int argc, const char** argv) {
         else if (arg.find('=') != std::string::npos) { key = arg.substr(0, arg.find('=')); value = arg.substr(arg.find('=') + 1); }
 
         if (key == "-h" || key == "--help") { print_usage(argv[0]); return 0; }
+        if (key == "--gpu-prerender") { opt.gpu_prerender = true; continue; }
         const bool known = key == "-f" || key == "--format" || key == "-W" || key == "--width" || key == "-H" || key == "--height" ||
                            key == "--scene" || key == "--spp" || key == "--depth" || key == "--seed" || key == "--gpus";
         if (!known) {
@@ -119,6 +122,7 @@ int main(int argc, const char** argv) {
         std::vector<int> devices;
         for (uint32_t i = 0; i < (opt.gpus ? opt.gpus : 1); i++) devices.push_back((int)i);
         HipRenderer renderer(devices);
+        renderer.set_gpu_prerender(opt.gpu_prerender);
         Camera cam;
         PathOptions path;
         path.spp = opt.spp; path.max_depth = opt.depth ? opt.depth : 1; path.seed = opt.seed;

@@ -33,6 +33,7 @@ public:
     void prerender(const Tools::Array<ECS::RenderEntity*>& entities) override;   // flatten in entity order + upload
     void render(Camera& camera) const override;                                  // fills camera.get_frame().d()
     void configure(const PathOptions& options) { path = options; }
+    void set_gpu_prerender(bool on) { gpu_prerender = on; }         // tessellate eprmf_gpu entities on the device (default: host)
     // scenes that are not entity lists (benchmark sphere fields)
     void set_spheres(const std::vector<float>& center_radius, const std::vector<rt3_material>& materials);
     void set_mesh(const std::vector<rt3_gface>& faces, const std::vector<float>& vertices_xyzw, const std::vector<rt3_material>& face_materials);
@@ -43,6 +44,7 @@ public:
 private:
     std::vector<rt3_ctx*> ctx;                      // one device context per GPU; frame rows are sharded over them
     PathOptions path;
+    bool gpu_prerender = false;
     size_t n_faces = 0, n_spheres = 0;
 };
 

@@ -81,6 +81,10 @@ def test_mode_r_through_the_cli_matches_the_oracle(tmp_path, oracle):
         faces, verts = oracle.merge([obj, sph])
         ref = oracle.render_mode_r(faces, verts, oracle.camera_update(160, 90), 160, 90)
         assert (tmp_path / "out.ppm").read_bytes() == oracle.ppm_bytes(ref)
+    # tessellating the sphere on the device gives the same file
+    rc, out, err = run("-f", "ppm", "-W", "160", "-H", "90", "--gpu-prerender", "gpu.ppm", cwd=str(tmp_path))
+    assert rc == 0, err
+    assert (tmp_path / "gpu.ppm").read_bytes() == oracle.ppm_bytes(ref)
     # default format is png (Main.cpp:76): same pixels, alpha 255
     rc, out, err = run("-W", "160", "-H", "90", "out.png", cwd=str(tmp_path))
     assert rc == 0, err
