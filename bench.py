@@ -111,7 +111,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RT3_BENCH_FORCE_DIST") == "1"     # the env knob rehearses the RCCL path on one GPU
+    if use_dist:
         dist.init_process_group(backend="nccl", device_id=dev)
 
     rt3 = importlib.import_module("raytracer-3_amd")
@@ -126,7 +127,7 @@ def main():
                               lens_radius=0.05, tile_rows=TILE_ROWS, tile_index=i, tile_count=world) for i in range(world)]
     my = params[rank]
     shard = importlib.import_module("raytracer-3_amd.shard")
-    g = shard.FrameGatherer(rt3, params, rank, dev)
+    g = shard.FrameGatherer(rt3, params, rank, dev, force_collective=use_dist and world == 1)
     tile = g.tile
     stream = torch.cuda.current_stream()
 
@@ -135,7 +136,7 @@ def main():
         g.gather()                                                       # N>1: ONE RCCL gather over xGMI (8.3 MB / N per peer)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +154,7 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     agg = torch.tensor([float(tests), float(casts), float(trace_ms)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg[:2], op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -208,7 +209,7 @@ def main():
             f.data[:] = g.frame.cpu().numpy().view(np.uint32)
             f.to_ppm(args.save_ppm)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

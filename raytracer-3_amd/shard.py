@@ -15,7 +15,8 @@ import torch.distributed as dist
 class FrameGatherer:
     """Owns the padded tile buffer of this rank and, on rank 0, the gather list and the assembled frame."""
 
-    def __init__(self, rt3, params_list, rank, device):
+    def __init__(self, rt3, params_list, rank, device, force_collective=False):
+        self.force_collective = force_collective           # run the gather even with one rank (rehearsal of the RCCL path)
         self.world = len(params_list)
         self.rank = rank
         self.rows = [rt3.rows_owned(p) for p in params_list]
@@ -32,12 +33,12 @@ class FrameGatherer:
             self.frame = torch.zeros((self.height, self.width), dtype=torch.int32, device=device)
             self.row_index = [torch.tensor([rt3.row_of_local(p, k) for k in range(n)], dtype=torch.long, device=device)
                               for p, n in zip(params_list, self.rows)]
-            if self.world > 1:
+            if self.world > 1 or force_collective:
                 self.gather_list = [torch.zeros_like(self.tile) for _ in range(self.world)]
 
     def gather(self):
         """Collects every rank's tile on rank 0 and returns the assembled frame there (None elsewhere)."""
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             dist.gather(self.tile, self.gather_list, dst=0)
             if self.rank == 0:
                 for i in range(self.world):
