@@ -755,6 +755,7 @@ struct rt3_ctx {
     hipStream_t last_stream = nullptr;
     uint64_t last_samples = 0;
     bool last_was_path = false;
+    bool rendered = false;
 };
 
 namespace {
@@ -1081,6 +1082,7 @@ int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint3
     ctx->last_stream = stream;
     ctx->last_samples = npix;
     ctx->last_was_path = false;
+    ctx->rendered = true;
     return 0;
 }
 
@@ -1113,6 +1115,7 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     ctx->last_stream = stream;
     ctx->last_samples = (uint64_t)npix * p->spp;
     ctx->last_was_path = true;
+    ctx->rendered = true;
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
     RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 8, stream));
     if (npix == 0) { RT3_HIP(hipEventRecord(ctx->ev_end, stream)); return 0; }
@@ -1208,7 +1211,7 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
     if (!ctx || !out) return RT3_E_ARG;
     RT3_HIP(hipSetDevice(ctx->device));
     std::memset(out, 0, sizeof *out);
-    if (ctx->ev_used == 0) return fail(ctx, RT3_E_STATE, "no render has been issued on this context");
+    if (!ctx->rendered) return fail(ctx, RT3_E_STATE, "no render has been issued on this context");
     RT3_HIP(hipEventSynchronize(ctx->ev_end));
     float ms = 0.0f;
     for (uint32_t i = 0; i < ctx->ev_used; i++) {

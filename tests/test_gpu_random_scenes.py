@@ -1,0 +1,69 @@
+"""Randomised parity: small random scenes (spheres of every material, overlapping and nested spheres, triangle soups, a ground
+quad, random look-at cameras, lens, strata, tiles) rendered by the HIP path and by the oracle must be bit-identical.  Seeds are
+fixed; the point is to reach rare branches (total internal reflection chains, absorbed metal rays, near-zero Lambert sums,
+queue overflow, ragged tails of the 4- and 32-sphere scan blocks, faces whose bounding spheres overlap many rays)."""
+import numpy as np
+import pytest
+
+from cases import hip_render, oracle_render, rt3
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(seed):
+    rng = np.random.RandomState(seed)
+    w, h = int(rng.randint(17, 72)), int(rng.randint(9, 48))
+    case = {}
+    n_sph = int(rng.choice([0, 1, 2, 3, 5, 31, 32, 33, 36, 67, 130]))
+    if n_sph:
+        cr = np.zeros((n_sph, 4), np.float32)
+        cr[:, :3] = rng.uniform(-4, 4, (n_sph, 3)) * np.float32([1.0, 0.5, 1.0]) + np.float32([0, 0, -6])
+        cr[:, 3] = rng.uniform(0.1, 1.2, n_sph)
+        if rng.rand() < 0.5:
+            cr[0] = (0.0, -1000.5, -6.0, 1000.0)                     # huge ground sphere
+        if n_sph > 2 and rng.rand() < 0.5:
+            cr[2, :3] = cr[1, :3]                                    # nested / concentric pair (hollow glass)
+            cr[2, 3] = cr[1, 3] * 0.7
+        mats = np.zeros(n_sph, rt3.MATERIAL)
+        mats["kind"] = rng.randint(0, 4, n_sph)
+        mats["rgb"] = rng.uniform(0.05, 1.0, (n_sph, 3))
+        mats["param"] = np.where(mats["kind"] == 3, rng.choice([1.5, 1.0 / 1.5, 2.4], n_sph), rng.uniform(0.0, 1.0, n_sph) * (rng.rand(n_sph) < 0.7))
+        case.update(spheres=cr, smats=mats)
+    n_tri = int(rng.choice([0, 0, 1, 4, 37, 300])) if n_sph else int(rng.choice([1, 5, 64, 257]))
+    if n_tri:
+        parts, fm = [], []
+        for i in range(n_tri):
+            c = rng.uniform(-3, 3, 3) * np.float32([1, 0.6, 1]) + np.float32([0, 0, -6])
+            p = [tuple(np.float32(c + rng.uniform(-0.8, 0.8, 3))) for _ in range(3)]
+            if i == 0:                                               # a big ground quad half
+                p = [(-8.0, -1.5, -1.0), (8.0, -1.5, -1.0), (0.0, -1.5, -14.0)]
+            if i == 1 and rng.rand() < 0.3:
+                p[2] = p[1]                                          # degenerate face (NaN normal)
+            e = rt3.create_triangle(*p, tuple(rng.uniform(0, 1, 3)))
+            parts.append(rt3.pre_render_entity(e))
+            m = np.zeros(1, rt3.MATERIAL)
+            m["kind"] = rng.randint(0, 4)
+            m["rgb"] = rng.uniform(0.1, 1.0, 3) * (4.0 if m["kind"][0] == 0 and rng.rand() < 0.3 else 1.0)
+            m["param"] = 1.5 if m["kind"][0] == 3 else rng.uniform(0, 0.6)
+            fm.append(m)
+        faces, verts = rt3.merge_entities(parts)
+        case.update(faces=faces, verts=verts, fmats=np.concatenate(fm) if rng.rand() < 0.8 else None)
+    cam = rt3.Camera().look_at(w, h, tuple(rng.uniform(-2, 2, 3) + np.float32([0, 0.5, 1.5])), (0.0, 0.0, -6.0), (0.0, 1.0, 0.0),
+                               float(rng.uniform(25, 70)), float(rng.uniform(4, 8)))
+    spp = int(rng.choice([1, 2, 3, 4, 9]))
+    tiles = int(rng.choice([1, 1, 2, 3]))
+    case.update(cam=cam.c, params=dict(width=w, height=h, spp=spp, max_depth=int(rng.choice([1, 2, 5, 12, 50])), seed=int(rng.randint(1, 1 << 30)),
+                                       flags=int(rng.randint(0, 4)), lens_radius=float(rng.choice([0.0, 0.0, 0.08])),
+                                       t_min=float(rng.choice([0.001, 0.001, 0.0, 0.01])), tile_rows=int(rng.choice([1, 3, 8])),
+                                       tile_index=int(rng.randint(0, tiles)), tile_count=tiles))
+    return case
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scene(renderer, seed):
+    case = random_case(seed)
+    want, casts = oracle_render(case, threads=16)
+    got = hip_render(renderer, case)
+    bad = got != want
+    assert not bad.any(), "seed %d: %d of %d pixels differ (params %r)" % (seed, bad.sum(), bad.size, case["params"])
+    assert renderer.stats().ray_casts == casts
