@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1]): the book's final random-spheres scene (484 
 dielectric), 1920x1080, 512 spp, depth 50, thin-lens camera, gamma 2.  One "step" = one full render of the frame
 (Mode X, rt3_render_path_device) with scene and camera already resident in HBM; the frame stays in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the same frame is sharded in interleaved 8-row blocks
+N > 1 (launched by torch.distributed.run, one rank per GPU): the same frame is sharded in interleaved rows
 (rt3_params.tile_*), every rank renders its rows, then ONE RCCL gather brings the packed RGBA8 rows to rank 0, which
 de-interleaves them on the device.  Total work is fixed, so scaling = "strong".
 
@@ -26,7 +26,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: must
 
 WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 512, 50
 SCENE_SEED, RENDER_SEED = 42, 1
-TILE_ROWS = 8
+TILE_ROWS = 1                        # single-row interleave: 1080 rows split exactly evenly over 2, 4 or 8 ranks
 FLOP_PER_SPHERE_TEST = 20.0          # 3 sub, 6 (b), 7 (c), 4 (D); hit-only sqrt/divide excluded
 FLOP_PER_TRI_TEST = 17.0             # conservative: every triangle test counted at its early-out cost
 PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X_MICROARCH.md:41

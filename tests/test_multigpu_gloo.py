@@ -46,7 +46,7 @@ def _worker(rank, world, port, tile_rows, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tile_rows", [(2, 8), (3, 5)])
+@pytest.mark.parametrize("world,tile_rows", [(2, 8), (3, 5), (2, 1)])
 def test_sharded_render_gathers_to_the_single_gpu_image(tmp_path, world, tile_rows):
     from cases import mode_x_cases, oracle_render
     out_path = str(tmp_path / "frame.npy")
