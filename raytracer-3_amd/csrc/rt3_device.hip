@@ -522,41 +522,40 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
                     done = true;
                 } else {
                     const bool front = dotf(dx, dy, dz, nx, ny, nz) < 0.0f;
-                    if (!front) { nx = -nx; ny = -ny; nz = -nz; }
+                    if (!front) { nx = -nx; ny = -ny; nz = -nz; }           // (the dot product is recomputed with the flipped normal below:
                     const uint32_t ctr = 1u + 8u * (P.depth + 1u);
                     float sx, sy, sz;                               // scattered direction before normalisation
                     float ar = m.x, ag = m.y, ab = m.z;
-                    if (mk == RT3_MAT_LAMBERT) {
-                        float vx, vy, vz;
+                    // work shared between material branches is done once for all lanes that need it: the random unit vector
+                    // (Lambert, fuzzy metal) and the mirror direction (metal, dielectric) — the wave executes every branch
+                    // that any lane takes, so merging them shortens the serialised shading
+                    const float dn = dotf(dx, dy, dz, nx, ny, nz);
+                    float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+                    if ((mk == RT3_MAT_LAMBERT) | ((mk == RT3_MAT_METAL) & (m.w > 0.0f)))
                         unit_vector(rnd(P.base, ctr), rnd(P.base, ctr + 1), vx, vy, vz);
+                    const float k2 = 2.0f * dn;
+                    const float mx = fma_(-k2, nx, dx), my = fma_(-k2, ny, dy), mz = fma_(-k2, nz, dz);   // reflect(d, n)
+                    if (mk == RT3_MAT_LAMBERT) {
                         sx = nx + vx; sy = ny + vy; sz = nz + vz;
                         if (__builtin_fabsf(sx) < 1e-8f && __builtin_fabsf(sy) < 1e-8f && __builtin_fabsf(sz) < 1e-8f) { sx = nx; sy = ny; sz = nz; }
                     } else if (mk == RT3_MAT_METAL) {
-                        const float k2 = 2.0f * dotf(dx, dy, dz, nx, ny, nz);
-                        float rx = fma_(-k2, nx, dx), ry = fma_(-k2, ny, dy), rz = fma_(-k2, nz, dz);
-                        const float inv = 1.0f / __builtin_sqrtf(dotf(rx, ry, rz, rx, ry, rz));
-                        rx *= inv; ry *= inv; rz *= inv;
+                        const float inv = 1.0f / __builtin_sqrtf(dotf(mx, my, mz, mx, my, mz));
+                        const float rx = mx * inv, ry = my * inv, rz = mz * inv;
                         sx = rx; sy = ry; sz = rz;
-                        if (m.w > 0.0f) {
-                            float vx, vy, vz;
-                            unit_vector(rnd(P.base, ctr), rnd(P.base, ctr + 1), vx, vy, vz);
-                            sx = fma_(m.w, vx, rx); sy = fma_(m.w, vy, ry); sz = fma_(m.w, vz, rz);
-                        }
+                        if (m.w > 0.0f) { sx = fma_(m.w, vx, rx); sy = fma_(m.w, vy, ry); sz = fma_(m.w, vz, rz); }
                         if (!(dotf(sx, sy, sz, nx, ny, nz) > 0.0f)) done = true;       // absorbed
-                    } else {                                        // dielectric
-                        const float ri = front ? 1.0f / m.w : m.w;
-                        float cosv = -dotf(dx, dy, dz, nx, ny, nz);
+                    } else {                                        // dielectric: m = (1/ior, r0(1/ior), r0(ior), ior), see rt3_set_spheres
+                        const float ri = front ? m.x : m.w;
+                        float cosv = -dn;
                         if (cosv > 1.0f) cosv = 1.0f;
                         const float s2 = fma_(-cosv, cosv, 1.0f);
                         const float sinv = __builtin_sqrtf(s2 > 0.0f ? s2 : 0.0f);
                         const bool cannot = ri * sinv > 1.0f;
-                        float r0 = (1.0f - ri) / (1.0f + ri);
-                        r0 = r0 * r0;
+                        const float r0 = front ? m.y : m.z;
                         const float xx = 1.0f - cosv, x2 = xx * xx, x5 = x2 * x2 * xx;
                         const float R = fma_(1.0f - r0, x5, r0);
                         if (cannot || R > rnd(P.base, ctr + 2)) {
-                            const float k2 = 2.0f * dotf(dx, dy, dz, nx, ny, nz);
-                            sx = fma_(-k2, nx, dx); sy = fma_(-k2, ny, dy); sz = fma_(-k2, nz, dz);
+                            sx = mx; sy = my; sz = mz;
                         } else {
                             const float ex = fma_(cosv, nx, dx) * ri, ey = fma_(cosv, ny, dy) * ri, ez = fma_(cosv, nz, dz) * ri;
                             const float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dotf(ex, ey, ez, ex, ey, ez)));
@@ -714,7 +713,15 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
     if ((double)r2f < r * r) r2f = __uint_as_float(__float_as_uint(r2f) + 1u);
     if (!(r2f >= 0.0f)) r2f = __builtin_inff();                    // NaN / inf vertices: always a candidate, the exact test decides
     bound[i] = make_float4((float)cx, (float)cy, (float)cz, r2f);
-    if (mats) { const rt3_material m = mats[i]; mat[i] = make_float4(m.rgb[0], m.rgb[1], m.rgb[2], m.param); kind[i] = m.kind; }
+    if (mats) {
+        const rt3_material m = mats[i];
+        if (m.kind == RT3_MAT_DIELECTRIC) {                         // same packing as pack_material() on the host
+            const float ri_f = 1.0f / m.param, ri_b = m.param;
+            float r0f = (1.0f - ri_f) / (1.0f + ri_f), r0b = (1.0f - ri_b) / (1.0f + ri_b);
+            mat[i] = make_float4(ri_f, r0f * r0f, r0b * r0b, m.param);
+        } else mat[i] = make_float4(m.rgb[0], m.rgb[1], m.rgb[2], m.param);
+        kind[i] = m.kind;
+    }
     else { mat[i] = make_float4(f.color[0], f.color[1], f.color[2], 0.0f); kind[i] = RT3_MAT_FLAT; }
 }
 
@@ -847,6 +854,16 @@ bool fastdiv_ok(uint32_t d, uint32_t n_max) {
         }
     }
     return true;
+}
+
+// Device form of a material: (rgb, param), except for a dielectric, whose attenuation is 1 and whose per-hit constants are
+// precomputed here with the float operations of DESIGN.md §4.5: (1/ior, r0 for ri = 1/ior, r0 for ri = ior, ior), r0 = ((1-ri)/(1+ri))^2.
+float4 pack_material(const rt3_material& m) {
+    if (m.kind != RT3_MAT_DIELECTRIC) return make_float4(m.rgb[0], m.rgb[1], m.rgb[2], m.param);
+    const float ri_f = 1.0f / m.param, ri_b = m.param;
+    float r0f = (1.0f - ri_f) / (1.0f + ri_f), r0b = (1.0f - ri_b) / (1.0f + ri_b);
+    r0f = r0f * r0f; r0b = r0b * r0b;
+    return make_float4(ri_f, r0f, r0b, m.param);
 }
 
 bool row_owned(const rt3_params* p, uint32_t y) {
@@ -1043,7 +1060,7 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
         if (materials[i].kind > RT3_MAT_DIELECTRIC) return fail(ctx, RT3_E_ARG, "unknown material kind");
         sph[i] = make_float4(s[0], s[1], s[2], s[3] * s[3]);
         invr[i] = 1.0f / s[3];
-        mat[i] = make_float4(materials[i].rgb[0], materials[i].rgb[1], materials[i].rgb[2], materials[i].param);
+        mat[i] = pack_material(materials[i]);
         kind[i] = materials[i].kind;
     }
     int rc;
