@@ -389,6 +389,125 @@ __global__ __launch_bounds__(kBlock) void k_mode_r_fast(const float4* __restrict
 
 // HAS_TRI / HAS_SPH compile the face loop / sphere loop (and the matching shading) in or out, so that a sphere-only
 // scene does not pay registers or code for the triangle path.
+// Refill: lanes whose path ended take the next samples of the wave's chunk (ballot + prefix count); a chunk of
+// kWorkChunk samples is fetched from the global queue with one atomic when the wave runs dry.
+__device__ __forceinline__ void refill_lanes(const TraceArgs& A, uint32_t lane, bool& alive, Path& P, uint32_t& chunk_next,
+                                             uint32_t& chunk_end, bool& exhausted) {
+    const unsigned long long need = __ballot(!alive);
+    if (need != 0ull && !exhausted) {
+        const uint32_t n_need = (uint32_t)__popcll(need);
+        const uint32_t rank = prefix_count(need);
+        uint32_t item = 0xFFFFFFFFu, taken = 0;
+        while (taken < n_need) {
+            if (chunk_next == chunk_end) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(A.work_counter, kWorkChunk);
+                b = __builtin_amdgcn_readfirstlane(b);
+                if (b >= A.total) { exhausted = true; break; }
+                chunk_next = b;
+                chunk_end = min(b + kWorkChunk, A.total);
+            }
+            const uint32_t k = min(n_need - taken, chunk_end - chunk_next);
+            if (!alive && rank >= taken && rank < taken + k) item = chunk_next + (rank - taken);
+            chunk_next += k;
+            taken += k;
+        }
+        if (item != 0xFFFFFFFFu) { start_path(A, item, P); alive = true; }
+    }
+}
+
+// Shade / scatter one ray cast of every live lane (book materials).  kind: 0 miss, 1 face, 2 sphere.
+template <bool HAS_TRI, bool HAS_SPH>
+__device__ __forceinline__ void shade_lane(const TraceArgs& A, Path& P, bool& alive, uint32_t kind, uint32_t ibest, float tbest) {
+    const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+    if (alive) {
+        bool done = false;
+        if (kind == 0) {
+            if (!(A.flags & RT3_FLAG_BLACK_BACKGROUND)) {
+                float r, g, b;
+                sky(dx, dy, dz, r, g, b);
+                P.lr = fma_(P.tr, r, P.lr); P.lg = fma_(P.tg, g, P.lg); P.lb = fma_(P.tb, b, P.lb);
+            }
+            done = true;
+        } else {
+            float4 m; uint32_t mk;
+            float px, py, pz, nx, ny, nz;
+            if (HAS_TRI && (!HAS_SPH || kind == 1)) {
+                m = A.tri_mat[ibest]; mk = A.tri_kind[ibest];
+                const float4 n = A.tri[(size_t)ibest * 4];
+                px = ox + tbest * dx; py = oy + tbest * dy; pz = oz + tbest * dz;
+                nx = n.x; ny = n.y; nz = n.z;
+            } else {
+                m = A.sph_mat[ibest]; mk = A.sph_kind[ibest];
+                const float4 s = A.sph[ibest];
+                const float invr = A.sph_invr[ibest];
+                px = fma_(tbest, dx, ox); py = fma_(tbest, dy, oy); pz = fma_(tbest, dz, oz);
+                nx = (px - s.x) * invr; ny = (py - s.y) * invr; nz = (pz - s.z) * invr;
+            }
+            if (mk == RT3_MAT_FLAT) {
+                P.lr = fma_(P.tr, m.x, P.lr); P.lg = fma_(P.tg, m.y, P.lg); P.lb = fma_(P.tb, m.z, P.lb);
+                done = true;
+            } else if (P.depth + 1 == A.max_depth) {
+                done = true;
+            } else {
+                const bool front = dotf(dx, dy, dz, nx, ny, nz) < 0.0f;
+                if (!front) { nx = -nx; ny = -ny; nz = -nz; }           // (the dot product is recomputed with the flipped normal below:
+                const uint32_t ctr = 1u + 8u * (P.depth + 1u);
+                float sx, sy, sz;                               // scattered direction before normalisation
+                float ar = m.x, ag = m.y, ab = m.z;
+                // work shared between material branches is done once for all lanes that need it: the random unit vector
+                // (Lambert, fuzzy metal) and the mirror direction (metal, dielectric) — the wave executes every branch
+                // that any lane takes, so merging them shortens the serialised shading
+                const float dn = dotf(dx, dy, dz, nx, ny, nz);
+                float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+                if ((mk == RT3_MAT_LAMBERT) | ((mk == RT3_MAT_METAL) & (m.w > 0.0f)))
+                    unit_vector(rnd(P.base, ctr), rnd(P.base, ctr + 1), vx, vy, vz);
+                const float k2 = 2.0f * dn;
+                const float mx = fma_(-k2, nx, dx), my = fma_(-k2, ny, dy), mz = fma_(-k2, nz, dz);   // reflect(d, n)
+                if (mk == RT3_MAT_LAMBERT) {
+                    sx = nx + vx; sy = ny + vy; sz = nz + vz;
+                    if (__builtin_fabsf(sx) < 1e-8f && __builtin_fabsf(sy) < 1e-8f && __builtin_fabsf(sz) < 1e-8f) { sx = nx; sy = ny; sz = nz; }
+                } else if (mk == RT3_MAT_METAL) {
+                    const float inv = 1.0f / __builtin_sqrtf(dotf(mx, my, mz, mx, my, mz));
+                    const float rx = mx * inv, ry = my * inv, rz = mz * inv;
+                    sx = rx; sy = ry; sz = rz;
+                    if (m.w > 0.0f) { sx = fma_(m.w, vx, rx); sy = fma_(m.w, vy, ry); sz = fma_(m.w, vz, rz); }
+                    if (!(dotf(sx, sy, sz, nx, ny, nz) > 0.0f)) done = true;       // absorbed
+                } else {                                        // dielectric: m = (1/ior, r0(1/ior), r0(ior), ior), see rt3_set_spheres
+                    const float ri = front ? m.x : m.w;
+                    float cosv = -dn;
+                    if (cosv > 1.0f) cosv = 1.0f;
+                    const float s2 = fma_(-cosv, cosv, 1.0f);
+                    const float sinv = __builtin_sqrtf(s2 > 0.0f ? s2 : 0.0f);
+                    const bool cannot = ri * sinv > 1.0f;
+                    const float r0 = front ? m.y : m.z;
+                    const float xx = 1.0f - cosv, x2 = xx * xx, x5 = x2 * x2 * xx;
+                    const float R = fma_(1.0f - r0, x5, r0);
+                    if (cannot || R > rnd(P.base, ctr + 2)) {
+                        sx = mx; sy = my; sz = mz;
+                    } else {
+                        const float ex = fma_(cosv, nx, dx) * ri, ey = fma_(cosv, ny, dy) * ri, ez = fma_(cosv, nz, dz) * ri;
+                        const float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dotf(ex, ey, ez, ex, ey, ez)));
+                        sx = fma_(par, nx, ex); sy = fma_(par, ny, ey); sz = fma_(par, nz, ez);
+                    }
+                    ar = ag = ab = 1.0f;
+                }
+                if (!done) {
+                    const float inv = 1.0f / __builtin_sqrtf(dotf(sx, sy, sz, sx, sy, sz));
+                    P.dx = sx * inv; P.dy = sy * inv; P.dz = sz * inv;
+                    P.ox = px; P.oy = py; P.oz = pz;
+                    P.tr *= ar; P.tg *= ag; P.tb *= ab;
+                    P.depth += 1;
+                }
+            }
+        }
+        if (done) {
+            A.rad[P.slot] = make_float4(P.lr, P.lg, P.lb, 0.0f);
+            alive = false;
+        }
+    }
+}
+
 // SPH_LDS: the sphere array (<= kSphLdsMax entries) is also copied to LDS once per block, for the per-lane gathers of
 // the exact evaluation (an LDS gather costs ~64 cycles, a global one an L2 round trip per candidate).
 template <bool HAS_TRI, bool HAS_SPH, bool SPH_LDS>
@@ -410,28 +529,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
     unsigned long long casts = 0;                                   // wave-uniform
 
     for (;;) {
-        // ---- refill: lanes whose path ended take the next samples of the wave's chunk (ballot + prefix count)
-        const unsigned long long need = __ballot(!alive);
-        if (need != 0ull && !exhausted) {
-            const uint32_t n_need = (uint32_t)__popcll(need);
-            const uint32_t rank = prefix_count(need);
-            uint32_t item = 0xFFFFFFFFu, taken = 0;
-            while (taken < n_need) {
-                if (chunk_next == chunk_end) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(A.work_counter, kWorkChunk);
-                    b = __builtin_amdgcn_readfirstlane(b);
-                    if (b >= A.total) { exhausted = true; break; }
-                    chunk_next = b;
-                    chunk_end = min(b + kWorkChunk, A.total);
-                }
-                const uint32_t k = min(n_need - taken, chunk_end - chunk_next);
-                if (!alive && rank >= taken && rank < taken + k) item = chunk_next + (rank - taken);
-                chunk_next += k;
-                taken += k;
-            }
-            if (item != 0xFFFFFFFFu) { start_path(A, item, P); alive = true; }
-        }
+        refill_lanes(A, lane, alive, P, chunk_next, chunk_end, exhausted);
         if (__ballot(alive) == 0ull) break;                         // waves are independent: no block-level barrier anywhere
         casts += (unsigned long long)__popcll(__ballot(alive));
 
@@ -490,93 +588,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
             }
         }
 
-        // ---- shade / scatter (book materials)
-        if (alive) {
-            bool done = false;
-            if (kind == 0) {
-                if (!(A.flags & RT3_FLAG_BLACK_BACKGROUND)) {
-                    float r, g, b;
-                    sky(dx, dy, dz, r, g, b);
-                    P.lr = fma_(P.tr, r, P.lr); P.lg = fma_(P.tg, g, P.lg); P.lb = fma_(P.tb, b, P.lb);
-                }
-                done = true;
-            } else {
-                float4 m; uint32_t mk;
-                float px, py, pz, nx, ny, nz;
-                if (HAS_TRI && (!HAS_SPH || kind == 1)) {
-                    m = A.tri_mat[ibest]; mk = A.tri_kind[ibest];
-                    const float4 n = A.tri[(size_t)ibest * 4];
-                    px = ox + tbest * dx; py = oy + tbest * dy; pz = oz + tbest * dz;
-                    nx = n.x; ny = n.y; nz = n.z;
-                } else {
-                    m = A.sph_mat[ibest]; mk = A.sph_kind[ibest];
-                    const float4 s = A.sph[ibest];
-                    const float invr = A.sph_invr[ibest];
-                    px = fma_(tbest, dx, ox); py = fma_(tbest, dy, oy); pz = fma_(tbest, dz, oz);
-                    nx = (px - s.x) * invr; ny = (py - s.y) * invr; nz = (pz - s.z) * invr;
-                }
-                if (mk == RT3_MAT_FLAT) {
-                    P.lr = fma_(P.tr, m.x, P.lr); P.lg = fma_(P.tg, m.y, P.lg); P.lb = fma_(P.tb, m.z, P.lb);
-                    done = true;
-                } else if (P.depth + 1 == A.max_depth) {
-                    done = true;
-                } else {
-                    const bool front = dotf(dx, dy, dz, nx, ny, nz) < 0.0f;
-                    if (!front) { nx = -nx; ny = -ny; nz = -nz; }           // (the dot product is recomputed with the flipped normal below:
-                    const uint32_t ctr = 1u + 8u * (P.depth + 1u);
-                    float sx, sy, sz;                               // scattered direction before normalisation
-                    float ar = m.x, ag = m.y, ab = m.z;
-                    // work shared between material branches is done once for all lanes that need it: the random unit vector
-                    // (Lambert, fuzzy metal) and the mirror direction (metal, dielectric) — the wave executes every branch
-                    // that any lane takes, so merging them shortens the serialised shading
-                    const float dn = dotf(dx, dy, dz, nx, ny, nz);
-                    float vx = 0.0f, vy = 0.0f, vz = 0.0f;
-                    if ((mk == RT3_MAT_LAMBERT) | ((mk == RT3_MAT_METAL) & (m.w > 0.0f)))
-                        unit_vector(rnd(P.base, ctr), rnd(P.base, ctr + 1), vx, vy, vz);
-                    const float k2 = 2.0f * dn;
-                    const float mx = fma_(-k2, nx, dx), my = fma_(-k2, ny, dy), mz = fma_(-k2, nz, dz);   // reflect(d, n)
-                    if (mk == RT3_MAT_LAMBERT) {
-                        sx = nx + vx; sy = ny + vy; sz = nz + vz;
-                        if (__builtin_fabsf(sx) < 1e-8f && __builtin_fabsf(sy) < 1e-8f && __builtin_fabsf(sz) < 1e-8f) { sx = nx; sy = ny; sz = nz; }
-                    } else if (mk == RT3_MAT_METAL) {
-                        const float inv = 1.0f / __builtin_sqrtf(dotf(mx, my, mz, mx, my, mz));
-                        const float rx = mx * inv, ry = my * inv, rz = mz * inv;
-                        sx = rx; sy = ry; sz = rz;
-                        if (m.w > 0.0f) { sx = fma_(m.w, vx, rx); sy = fma_(m.w, vy, ry); sz = fma_(m.w, vz, rz); }
-                        if (!(dotf(sx, sy, sz, nx, ny, nz) > 0.0f)) done = true;       // absorbed
-                    } else {                                        // dielectric: m = (1/ior, r0(1/ior), r0(ior), ior), see rt3_set_spheres
-                        const float ri = front ? m.x : m.w;
-                        float cosv = -dn;
-                        if (cosv > 1.0f) cosv = 1.0f;
-                        const float s2 = fma_(-cosv, cosv, 1.0f);
-                        const float sinv = __builtin_sqrtf(s2 > 0.0f ? s2 : 0.0f);
-                        const bool cannot = ri * sinv > 1.0f;
-                        const float r0 = front ? m.y : m.z;
-                        const float xx = 1.0f - cosv, x2 = xx * xx, x5 = x2 * x2 * xx;
-                        const float R = fma_(1.0f - r0, x5, r0);
-                        if (cannot || R > rnd(P.base, ctr + 2)) {
-                            sx = mx; sy = my; sz = mz;
-                        } else {
-                            const float ex = fma_(cosv, nx, dx) * ri, ey = fma_(cosv, ny, dy) * ri, ez = fma_(cosv, nz, dz) * ri;
-                            const float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dotf(ex, ey, ez, ex, ey, ez)));
-                            sx = fma_(par, nx, ex); sy = fma_(par, ny, ey); sz = fma_(par, nz, ez);
-                        }
-                        ar = ag = ab = 1.0f;
-                    }
-                    if (!done) {
-                        const float inv = 1.0f / __builtin_sqrtf(dotf(sx, sy, sz, sx, sy, sz));
-                        P.dx = sx * inv; P.dy = sy * inv; P.dz = sz * inv;
-                        P.ox = px; P.oy = py; P.oz = pz;
-                        P.tr *= ar; P.tg *= ag; P.tb *= ab;
-                        P.depth += 1;
-                    }
-                }
-            }
-            if (done) {
-                A.rad[P.slot] = make_float4(P.lr, P.lg, P.lb, 0.0f);
-                alive = false;
-            }
-        }
+        shade_lane<HAS_TRI, HAS_SPH>(A, P, alive, kind, ibest, tbest);
     }
     if (lane == 0 && casts != 0) atomicAdd(A.cast_counter, casts);
 }
