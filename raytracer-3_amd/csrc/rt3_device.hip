@@ -593,6 +593,175 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
     if (lane == 0 && casts != 0) atomicAdd(A.cast_counter, casts);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Mode X, sphere scenes that fit one LDS image: the candidate filter on the MATRIX cores
+// ------------------------------------------------------------------------------------------------------
+// The discriminant sign of every (sphere, ray) pair is a dense contraction:
+//     h_ij  = C_j.d_i - o_i.d_i                                   = sum_t a_t  b_t ,  a = (dx,dy,dz,-o.d),            b = (Cx,Cy,Cz,1)
+//     c'_ij = |C_j - o_i|^2 - r_j^2 - margin_ij                   = sum_t a'_t b'_t,  a' = (-2ox,-2oy,-2oz,1,|o|^2(1-eps)), b' = (Cx,Cy,Cz,K_j,1)
+//     K_j   = (|C_j|^2 - r_j^2) - eps (|C_j|^2 + r_j^2),   margin_ij = eps (|C_j|^2 + r_j^2 + |o_i|^2),   candidate iff h^2 - c' >= 0
+// It runs on v_mfma_f32_32x32x16_bf16 with every f32 factor split into three bf16 parts (x = H + M + L) and the six leading
+// cross products (HH, HM, MH, HL, LH, MM) laid out along K: 4 x 6 = 24 of 32 K-slots for h, 5 x 6 = 30 of 32 for c' — f32-level
+// accuracy at 1/4 of the cycles the 10 VALU instructions per pair cost.  The expanded form cancels catastrophically and is
+// therefore used ONLY as a conservative filter: eps = 2e-5 covers its error (<= ~2e-6 (|C|+|o|)^2) several times over, and the
+// surviving pairs go through the same exact f32 evaluation as in k_trace, so images stay bit-identical.
+// A = spheres (rows), B = rays (columns): lane l then holds, for ray (l & 31) of the current half-wave, 16 results in its
+// accumulator registers (rows (g&3) + 8(g>>2) + 4(l>>5)), turns their signs into a 16-bit mask with 2 VALU ops per pair and
+// queues the candidates for the ray's own lane.
+constexpr int      kMB        = 1024;      // threads per workgroup of k_trace_mfma (one workgroup per CU, 4 waves per SIMD)
+constexpr int      kMQ        = 16;        // slots per candidate sub-queue (two writers per ray)
+constexpr uint32_t kMfmaSphMax = 512;      // 16 row blocks x 4 operand fragments x 1 KiB = 64 KiB of LDS
+constexpr float    kFilterEps = 2e-5f;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// K-slot tables, shared by the host (sphere fragments) and the device (ray fragments).  part: 0 = H, 1 = M, 2 = L, 3 = zero.
+__host__ __device__ constexpr int combo_ray_part(int c) { return c == 0 ? 0 : c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 0 : c == 4 ? 2 : c == 5 ? 1 : 3; }
+__host__ __device__ constexpr int combo_sph_part(int c) { return c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 0 : c == 3 ? 2 : c == 4 ? 0 : c == 5 ? 1 : 3; }
+// product 0 (h): slot = 4 combo + term;  product 1 (c'): slot = 5 combo + term (30, 31 unused)
+__host__ __device__ constexpr int slot_combo(int product, int s) { return product == 0 ? s / 4 : (s < 30 ? s / 5 : 7); }
+__host__ __device__ constexpr int slot_term(int product, int s) { return product == 0 ? s % 4 : s % 5; }
+
+__host__ __device__ inline uint32_t bf16_rn(float x) {            // round to nearest even, finite inputs
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__host__ __device__ inline float bf16_up(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+__host__ __device__ inline void split3(float x, uint32_t* parts /*[3]*/) {
+    parts[0] = bf16_rn(x);
+    const float r1 = x - bf16_up(parts[0]);
+    parts[1] = bf16_rn(r1);
+    parts[2] = bf16_rn(r1 - bf16_up(parts[1]));
+}
+
+__global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32x4* __restrict__ frags, uint32_t n_blocks) {
+    extern __shared__ u32x4 lds_dyn[];
+    u32x4* s_frag = lds_dyn;                                                   // [n_blocks][4][64]
+    float4* s_sph = reinterpret_cast<float4*>(s_frag + (size_t)n_blocks * 256);   // [n_blocks * 32] (cx, cy, cz, r^2) for the exact test
+    uint16_t* s_q = reinterpret_cast<uint16_t*>(s_sph + (size_t)n_blocks * 32);  // [2][kMQ][kMB]
+    const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5, col = lane & 31;
+    for (uint32_t k = tid; k < n_blocks * 256; k += kMB) s_frag[k] = frags[k];
+    for (uint32_t k = tid; k < n_blocks * 32; k += kMB) s_sph[k] = k < A.n_sph ? A.sph[k] : kPadSphere;
+    __syncthreads();                                                            // the only barrier
+
+    Path P;
+    P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
+    P.tr = P.tg = P.tb = 0.0f; P.lr = P.lg = P.lb = 0.0f; P.slot = 0; P.base = 0; P.depth = 0;
+    bool alive = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    unsigned long long casts = 0;
+
+    for (;;) {
+        refill_lanes(A, lane, alive, P, chunk_next, chunk_end, exhausted);
+        const unsigned long long live = __ballot(alive);
+        if (live == 0ull) break;
+        casts += (unsigned long long)__popcll(live);
+        const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+
+        // ---- ray-side K vectors of this lane's own ray, as bf16 parts
+        uint32_t ra[4][3], rb[5][3];                                // [term][part]
+        {
+            const float od = dotf(ox, oy, oz, dx, dy, dz), oo = dotf(ox, oy, oz, ox, oy, oz);
+            split3(dx, ra[0]); split3(dy, ra[1]); split3(dz, ra[2]); split3(-od, ra[3]);
+            split3(-2.0f * ox, rb[0]); split3(-2.0f * oy, rb[1]); split3(-2.0f * oz, rb[2]);
+            rb[3][0] = 0x3F80u; rb[3][1] = 0u; rb[3][2] = 0u;       // the constant 1
+            split3(oo * (1.0f - kFilterEps), rb[4]);
+        }
+        // own[q][d]: dword d (K elements 2d, 2d+1) of MFMA q (0,1: h-product slots 0-15 / 16-31; 2,3: c'-product)
+        // B fragment of set S (rays 32S .. 32S+31 as columns): lane (S, col) needs elements 8*half .. 8*half+7 of ray 32S+col.
+        u32x4 bop[2][4];
+        {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t own[8];
+#pragma unroll
+                for (int d = 0; d < 8; d++) {
+                    uint32_t e[2];
+#pragma unroll
+                    for (int z = 0; z < 2; z++) {
+                        const int product = q >> 1, sl = 16 * (q & 1) + 2 * d + z;
+                        const int part = combo_ray_part(slot_combo(product, sl)), term = slot_term(product, sl);
+                        e[z] = part == 3 ? 0u : (product == 0 ? ra[term][part] : rb[term][part]);
+                    }
+                    own[d] = e[0] | (e[1] << 16);
+                }
+                // lanes 0-31 keep their elements 0-7 for set 0 and need the partner's 0-7 for set 1; lanes 32-63 the mirror image
+                uint32_t recv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) recv[i] = (uint32_t)__shfl_xor((int)(half ? own[i] : own[4 + i]), 32);
+                bop[0][q] = half ? u32x4{ recv[0], recv[1], recv[2], recv[3] } : u32x4{ own[0], own[1], own[2], own[3] };
+                bop[1][q] = half ? u32x4{ own[4], own[5], own[6], own[7] } : u32x4{ recv[0], recv[1], recv[2], recv[3] };
+            }
+        }
+        const bool col_live[2] = { ((live >> col) & 1ull) != 0, ((live >> (32 + col)) & 1ull) != 0 };
+
+        // ---- nearest hit: exact evaluation of queued candidates (ties: lower sphere index, as the sequential loop)
+        float tbest = __builtin_inff();
+        uint32_t ibest = 0, kind = 0;
+        uint32_t nq[2] = { 0, 0 };
+        auto eval = [&](uint32_t j) {
+            const float4 s = s_sph[j];
+            const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+            const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+            const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+            const float disc = fma_(h, h, -c);
+            if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return;
+            const float sq = __builtin_sqrtf(disc);
+            float t = h - sq;
+            if (!(t > A.t_min)) t = h + sq;
+            if (t > A.t_min && (t < tbest || (t == tbest && j < ibest))) { tbest = t; ibest = j; kind = 2; }
+        };
+        auto flush = [&]() {                                        // wave-uniform: both writers of a ray's queues are in this wave
+            const uint32_t n_own = half ? nq[1] : nq[0];
+            const uint32_t n_oth = (uint32_t)__shfl_xor((int)(half ? nq[0] : nq[1]), 32);
+            const uint16_t* q_own = s_q + (size_t)half * kMQ * kMB + tid;
+            const uint16_t* q_oth = s_q + (size_t)half * kMQ * kMB + (tid ^ 32u);
+            for (uint32_t i = 0; i < n_own; i++) eval(q_own[i * kMB]);
+            for (uint32_t i = 0; i < n_oth; i++) eval(q_oth[i * kMB]);
+            nq[0] = 0; nq[1] = 0;
+        };
+
+        for (uint32_t blk = 0; blk < n_blocks; blk++) {
+            const u32x4* fr = s_frag + (size_t)blk * 256 + lane;
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
+            uint32_t cm[2];
+#pragma unroll
+            for (int S = 0; S < 2; S++) {
+                const f32x16 zero = { 0 };
+                f32x16 hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, bop[S][0]), zero, 0, 0, 0);
+                hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bop[S][1]), hh, 0, 0, 0);
+                f32x16 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, bop[S][2]), zero, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, bop[S][3]), cc, 0, 0, 0);
+                uint32_t neg = 0xFFFFFFFFu;
+#pragma unroll
+                for (int g = 0; g < 16; g++) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(fma_(hh[g], hh[g], -cc[g])), 31);
+                cm[S] = col_live[S] ? (~neg & 0xFFFFu) : 0u;        // bit 15-g <-> accumulator register g
+            }
+            if (__ballot((nq[0] + (uint32_t)__popc(cm[0]) > (uint32_t)kMQ) || (nq[1] + (uint32_t)__popc(cm[1]) > (uint32_t)kMQ)) != 0ull) flush();
+#pragma unroll
+            for (int S = 0; S < 2; S++) {
+                uint16_t* q = s_q + (size_t)S * kMQ * kMB + tid;
+                uint32_t m = cm[S];
+                while (m != 0) {
+                    const uint32_t top = 31u - (uint32_t)__builtin_clz(m);
+                    m &= ~(1u << top);
+                    const uint32_t g = 15u - top;
+                    q[nq[S] * kMB] = (uint16_t)(blk * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half);
+                    nq[S]++;
+                }
+            }
+        }
+        flush();
+        shade_lane<false, true>(A, P, alive, kind, ibest, tbest);
+    }
+    if (lane == 0 && casts != 0) atomicAdd(A.cast_counter, casts);
+}
+
 // reduce pass (what reduce_v1.glsl:66-76 was meant to be): samples are summed per pixel in sample order.
 __global__ __launch_bounds__(kBlock) void k_accumulate(const float4* __restrict__ rad, float4* __restrict__ accum,
                                                       uint32_t npix, uint32_t ns, int first) {
@@ -756,7 +925,7 @@ struct rt3_ctx {
     rt3_material* d_face_mats_in = nullptr; uint32_t* d_error = nullptr;
     // spheres
     uint32_t n_sph = 0;
-    float4* d_sph = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
+    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
     // work buffers
     float4* d_rad = nullptr; size_t rad_entries = 0;
@@ -878,6 +1047,40 @@ float4 pack_material(const rt3_material& m) {
     return make_float4(ri_f, r0f, r0b, m.param);
 }
 
+// Sphere-side operand fragments of k_trace_mfma: [row block of 32 spheres][4 MFMA operands][64 lanes] x 8 bf16.
+// Lane l holds, for sphere (l & 31) of the block, K elements 8 (l >> 5) .. +7 of the operand; padding rows can never be candidates.
+std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n) {
+    const uint32_t blocks = (n + 31u) / 32u;
+    std::vector<uint32_t> out((size_t)blocks * 4 * 64 * 4, 0u);
+    for (uint32_t blk = 0; blk < blocks; blk++)
+        for (uint32_t row = 0; row < 32; row++) {
+            const uint32_t j = blk * 32 + row;
+            uint32_t b0[4][3], b1[5][3];                            // [term][part]
+            if (j < n) {
+                const float* s = center_radius + 4 * (size_t)j;
+                const double c2 = (double)s[0] * s[0] + (double)s[1] * s[1] + (double)s[2] * s[2], r2 = (double)s[3] * s[3];
+                const float kj = (float)((c2 - r2) - (double)kFilterEps * (c2 + r2));
+                split3(s[0], b0[0]); split3(s[1], b0[1]); split3(s[2], b0[2]);
+                split3(s[0], b1[0]); split3(s[1], b1[1]); split3(s[2], b1[2]); split3(kj, b1[3]);
+            } else {
+                for (int t = 0; t < 3; t++) for (int p = 0; p < 3; p++) { b0[t][p] = 0; b1[t][p] = 0; }
+                split3(1e30f, b1[3]);                               // c' = +1e30: the discriminant is hugely negative
+            }
+            b0[3][0] = 0x3F80u; b0[3][1] = 0; b0[3][2] = 0;         // the constant 1
+            b1[4][0] = 0x3F80u; b1[4][1] = 0; b1[4][2] = 0;
+            for (int q = 0; q < 4; q++)
+                for (uint32_t hh = 0; hh < 2; hh++)
+                    for (int e = 0; e < 8; e++) {
+                        const int product = q >> 1, sl = 16 * (q & 1) + 8 * (int)hh + e;
+                        const int part = combo_sph_part(slot_combo(product, sl)), term = slot_term(product, sl);
+                        const uint32_t v = part == 3 ? 0u : (product == 0 ? b0[term][part] : b1[term][part]);
+                        const size_t dword = (((size_t)blk * 4 + q) * 64 + (hh * 32 + row)) * 4 + e / 2;
+                        out[dword] |= v << (16 * (e & 1));
+                    }
+        }
+    return out;
+}
+
 bool row_owned(const rt3_params* p, uint32_t y) {
     if (p->tile_count <= 1) return true;
     return ((y / p->tile_rows) % p->tile_count) == p->tile_index;
@@ -936,7 +1139,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_sph, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
+    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_out, ctx->d_work, ctx->d_casts };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -1076,6 +1279,8 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
         kind[i] = materials[i].kind;
     }
     int rc;
+    if ((rc = upload(ctx, &ctx->d_sph_frag, n <= kMfmaSphMax ? build_sphere_frags(center_radius, n) : std::vector<uint32_t>())))
+        return rc;
     if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
         (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
         return rc;
@@ -1193,8 +1398,14 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     const size_t lds_bytes = sph_lds ? (size_t)ctx->n_sph * sizeof(float4) : 0;
     const TraceKernel kernel = has_tri ? (has_sph ? (sph_lds ? k_trace<true, true, true> : k_trace<true, true, false>) : k_trace<true, false, false>)
                                        : (sph_lds ? k_trace<false, true, true> : k_trace<false, true, false>);
+    // sphere-only scenes of <= 512 spheres: candidate filter on the matrix cores (RT3_NO_MFMA=1 keeps the VALU scan, for A/B runs)
+    const bool use_mfma = !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && ctx->d_sph_frag && !getenv("RT3_NO_MFMA");
+    const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
+    const size_t mfma_lds = (size_t)mfma_blocks * (4096 + 512) + (size_t)2 * kMQ * kMB * sizeof(uint16_t);
+    if (use_mfma) RT3_HIP(hipFuncSetAttribute((const void*)k_trace_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
     int per_cu = 0;
-    RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes));
+    if (use_mfma) RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mfma, kMB, mfma_lds));
+    else RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes));
     if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_trace does not fit on a CU");
     per_cu = std::min(per_cu, 8);
 
@@ -1202,13 +1413,15 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
         const uint32_t ns = std::min(batch, p->spp - s0);
         A.s0 = s0;
         A.total = npix * ns;
-        const uint32_t want_blocks = (A.total + kWorkChunk * 4 - 1) / (kWorkChunk * 4);
+        const uint32_t waves_per_block = use_mfma ? kMB / 64 : kBlock / 64;
+        const uint32_t want_blocks = (A.total + kWorkChunk * waves_per_block - 1) / (kWorkChunk * waves_per_block);
         const uint32_t grid = std::max(1u, std::min<uint32_t>((uint32_t)(ctx->num_cu * per_cu), want_blocks));
         hipEvent_t a, b;
         if ((rc = take_event_pair(ctx, &a, &b))) return rc;
         RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
         RT3_HIP(hipEventRecord(a, stream));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
+        if (use_mfma) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), mfma_lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
+        else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipEventRecord(b, stream));
         hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
