@@ -609,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
 // accumulator registers (rows (g&3) + 8(g>>2) + 4(l>>5)), turns their signs into a 16-bit mask with 2 VALU ops per pair and
 // queues the candidates for the ray's own lane.
 constexpr int      kMB        = 1024;      // threads per workgroup of k_trace_mfma (one workgroup per CU, 4 waves per SIMD)
-constexpr int      kMQ        = 16;        // slots per candidate sub-queue (two writers per ray)
+constexpr int      kMQ        = 32;        // one-byte slots per candidate sub-queue (two writers per ray); flushed above 16
 constexpr uint32_t kMfmaSphMax = 512;      // 16 row blocks x 4 operand fragments x 1 KiB = 64 KiB of LDS
 constexpr float    kFilterEps = 2e-5f;
 
@@ -641,8 +641,8 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;                                                   // [n_blocks][4][64]
     float4* s_sph = reinterpret_cast<float4*>(s_frag + (size_t)n_blocks * 256);   // [n_blocks * 32] (cx, cy, cz, r^2) for the exact test
-    uint16_t* s_q = reinterpret_cast<uint16_t*>(s_sph + (size_t)n_blocks * 32);  // [2][kMQ][kMB]
-    const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5, col = lane & 31;
+    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_sph + (size_t)n_blocks * 32);    // [2][kMQ][kMB], entry = row block << 4 | mask bit
+    const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5;
     for (uint32_t k = tid; k < n_blocks * 256; k += kMB) s_frag[k] = frags[k];
     for (uint32_t k = tid; k < n_blocks * 32; k += kMB) s_sph[k] = k < A.n_sph ? A.sph[k] : kPadSphere;
     __syncthreads();                                                            // the only barrier
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             split3(dx, ra[0]); split3(dy, ra[1]); split3(dz, ra[2]); split3(-od, ra[3]);
             split3(-2.0f * ox, rb[0]); split3(-2.0f * oy, rb[1]); split3(-2.0f * oz, rb[2]);
             rb[3][0] = 0x3F80u; rb[3][1] = 0u; rb[3][2] = 0u;       // the constant 1
-            split3(oo * (1.0f - kFilterEps), rb[4]);
+            split3(alive ? oo * (1.0f - kFilterEps) : 1e30f, rb[4]);   // a dead lane's column can never produce a candidate
         }
         // own[q][d]: dword d (K elements 2d, 2d+1) of MFMA q (0,1: h-product slots 0-15 / 16-31; 2,3: c'-product)
         // B fragment of set S (rays 32S .. 32S+31 as columns): lane (S, col) needs elements 8*half .. 8*half+7 of ray 32S+col.
@@ -697,13 +697,16 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
                 bop[1][q] = half ? u32x4{ own[4], own[5], own[6], own[7] } : u32x4{ recv[0], recv[1], recv[2], recv[3] };
             }
         }
-        const bool col_live[2] = { ((live >> col) & 1ull) != 0, ((live >> (32 + col)) & 1ull) != 0 };
 
         // ---- nearest hit: exact evaluation of queued candidates (ties: lower sphere index, as the sequential loop)
         float tbest = __builtin_inff();
         uint32_t ibest = 0, kind = 0;
         uint32_t nq[2] = { 0, 0 };
-        auto eval = [&](uint32_t j) {
+        // queue entry e = (row block << 4) | bit, bit = 15 - accumulator register g; written by lane half w:
+        // sphere index = 32 (e >> 4) + (g & 3) + 8 (g >> 2) + 4 w
+        auto eval = [&](uint32_t e, uint32_t w) {
+            const uint32_t g = 15u - (e & 15u);
+            const uint32_t j = (e >> 4) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * w;
             const float4 s = s_sph[j];
             const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
             const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
@@ -715,13 +718,14 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             if (!(t > A.t_min)) t = h + sq;
             if (t > A.t_min && (t < tbest || (t == tbest && j < ibest))) { tbest = t; ibest = j; kind = 2; }
         };
+        uint8_t* const q0 = s_q + tid;                              // this lane's sub-queue of set 0; set 1 is kMQ * kMB further
         auto flush = [&]() {                                        // wave-uniform: both writers of a ray's queues are in this wave
             const uint32_t n_own = half ? nq[1] : nq[0];
             const uint32_t n_oth = (uint32_t)__shfl_xor((int)(half ? nq[0] : nq[1]), 32);
-            const uint16_t* q_own = s_q + (size_t)half * kMQ * kMB + tid;
-            const uint16_t* q_oth = s_q + (size_t)half * kMQ * kMB + (tid ^ 32u);
-            for (uint32_t i = 0; i < n_own; i++) eval(q_own[i * kMB]);
-            for (uint32_t i = 0; i < n_oth; i++) eval(q_oth[i * kMB]);
+            const uint8_t* q_own = s_q + (size_t)half * kMQ * kMB + tid;
+            const uint8_t* q_oth = s_q + (size_t)half * kMQ * kMB + (tid ^ 32u);
+            for (uint32_t i = 0; i < n_own; i++) eval(q_own[i * kMB], half);
+            for (uint32_t i = 0; i < n_oth; i++) eval(q_oth[i * kMB], half ^ 1u);
             nq[0] = 0; nq[1] = 0;
         };
 
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             const u32x4* fr = s_frag + (size_t)blk * 256 + lane;
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
             const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
-            uint32_t cm[2];
+            if (__ballot((nq[0] > 16u) || (nq[1] > 16u)) != 0ull) flush();     // a block adds at most 16 entries per sub-queue
 #pragma unroll
             for (int S = 0; S < 2; S++) {
                 const f32x16 zero = { 0 };
@@ -740,18 +744,13 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
                 uint32_t neg = 0xFFFFFFFFu;
 #pragma unroll
                 for (int g = 0; g < 16; g++) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(fma_(hh[g], hh[g], -cc[g])), 31);
-                cm[S] = col_live[S] ? (~neg & 0xFFFFu) : 0u;        // bit 15-g <-> accumulator register g
-            }
-            if (__ballot((nq[0] + (uint32_t)__popc(cm[0]) > (uint32_t)kMQ) || (nq[1] + (uint32_t)__popc(cm[1]) > (uint32_t)kMQ)) != 0ull) flush();
-#pragma unroll
-            for (int S = 0; S < 2; S++) {
-                uint16_t* q = s_q + (size_t)S * kMQ * kMB + tid;
-                uint32_t m = cm[S];
-                while (m != 0) {
+                uint32_t m = ~neg & 0xFFFFu;                        // bit 15-g <-> accumulator register g
+                uint8_t* q = q0 + (size_t)S * kMQ * kMB + nq[S] * kMB;
+                while (m != 0) {                                    // ascending sphere index = descending bit
                     const uint32_t top = 31u - (uint32_t)__builtin_clz(m);
-                    m &= ~(1u << top);
-                    const uint32_t g = 15u - top;
-                    q[nq[S] * kMB] = (uint16_t)(blk * 32u + (g & 3u) + 8u * (g >> 2) + 4u * half);
+                    m ^= 1u << top;
+                    *q = (uint8_t)((blk << 4) | top);
+                    q += kMB;
                     nq[S]++;
                 }
             }
@@ -1401,7 +1400,7 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     // sphere-only scenes of <= 512 spheres: candidate filter on the matrix cores (RT3_NO_MFMA=1 keeps the VALU scan, for A/B runs)
     const bool use_mfma = !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && ctx->d_sph_frag && !getenv("RT3_NO_MFMA");
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
-    const size_t mfma_lds = (size_t)mfma_blocks * (4096 + 512) + (size_t)2 * kMQ * kMB * sizeof(uint16_t);
+    const size_t mfma_lds = (size_t)mfma_blocks * (4096 + 512) + (size_t)2 * kMQ * kMB;
     if (use_mfma) RT3_HIP(hipFuncSetAttribute((const void*)k_trace_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
     int per_cu = 0;
     if (use_mfma) RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mfma, kMB, mfma_lds));
