@@ -96,6 +96,8 @@ typedef struct rt3_stats {
     float    total_ms;           /* first launch -> last launch of the call (device time)            */
     uint32_t launches;           /* launches of the dominant kernel                                  */
     uint32_t n_spheres, n_faces;
+    uint32_t _pad;
+    uint64_t mfma_instructions;  /* v_mfma_f32_32x32x16_bf16 wave-instructions issued by the candidate filter (0: VALU scan) */
 } rt3_stats;
 
 typedef struct rt3_ctx rt3_ctx;

@@ -417,8 +417,10 @@ __device__ __forceinline__ void refill_lanes(const TraceArgs& A, uint32_t lane, 
 }
 
 // Shade / scatter one ray cast of every live lane (book materials).  kind: 0 miss, 1 face, 2 sphere.
+// The four per-sphere arrays read at a hit are parameters: global memory in k_trace, LDS copies in k_trace_mfma.
 template <bool HAS_TRI, bool HAS_SPH>
-__device__ __forceinline__ void shade_lane(const TraceArgs& A, Path& P, bool& alive, uint32_t kind, uint32_t ibest, float tbest) {
+__device__ __forceinline__ void shade_lane(const TraceArgs& A, Path& P, bool& alive, uint32_t kind, uint32_t ibest, float tbest,
+                                           const float4* sph, const float* sph_invr, const float4* sph_mat, const uint32_t* sph_kind) {
     const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
     if (alive) {
         bool done = false;
@@ -438,9 +440,9 @@ __device__ __forceinline__ void shade_lane(const TraceArgs& A, Path& P, bool& al
                 px = ox + tbest * dx; py = oy + tbest * dy; pz = oz + tbest * dz;
                 nx = n.x; ny = n.y; nz = n.z;
             } else {
-                m = A.sph_mat[ibest]; mk = A.sph_kind[ibest];
-                const float4 s = A.sph[ibest];
-                const float invr = A.sph_invr[ibest];
+                m = sph_mat[ibest]; mk = sph_kind[ibest];
+                const float4 s = sph[ibest];
+                const float invr = sph_invr[ibest];
                 px = fma_(tbest, dx, ox); py = fma_(tbest, dy, oy); pz = fma_(tbest, dz, oz);
                 nx = (px - s.x) * invr; ny = (py - s.y) * invr; nz = (pz - s.z) * invr;
             }
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
             }
         }
 
-        shade_lane<HAS_TRI, HAS_SPH>(A, P, alive, kind, ibest, tbest);
+        shade_lane<HAS_TRI, HAS_SPH>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
     }
     if (lane == 0 && casts != 0) atomicAdd(A.cast_counter, casts);
 }
@@ -641,10 +643,19 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;                                                   // [n_blocks][4][64]
     float4* s_sph = reinterpret_cast<float4*>(s_frag + (size_t)n_blocks * 256);   // [n_blocks * 32] (cx, cy, cz, r^2) for the exact test
-    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_sph + (size_t)n_blocks * 32);    // [2][kMQ][kMB], entry = row block << 4 | mask bit
+    float4* s_mat = s_sph + (size_t)n_blocks * 32;                               // materials, kinds, 1/r: read at every hit
+    float* s_invr = reinterpret_cast<float*>(s_mat + (size_t)n_blocks * 32);
+    uint32_t* s_kind = reinterpret_cast<uint32_t*>(s_invr + (size_t)n_blocks * 32);
+    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_kind + (size_t)n_blocks * 32);   // [2][kMQ][kMB], entry = row block << 4 | mask bit
     const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5;
     for (uint32_t k = tid; k < n_blocks * 256; k += kMB) s_frag[k] = frags[k];
-    for (uint32_t k = tid; k < n_blocks * 32; k += kMB) s_sph[k] = k < A.n_sph ? A.sph[k] : kPadSphere;
+    for (uint32_t k = tid; k < n_blocks * 32; k += kMB) {
+        const bool in = k < A.n_sph;
+        s_sph[k] = in ? A.sph[k] : kPadSphere;
+        s_mat[k] = in ? A.sph_mat[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_invr[k] = in ? A.sph_invr[k] : 0.0f;
+        s_kind[k] = in ? A.sph_kind[k] : 0u;
+    }
     __syncthreads();                                                            // the only barrier
 
     Path P;
@@ -653,13 +664,14 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     bool alive = false;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
-    unsigned long long casts = 0;
+    unsigned long long casts = 0, iters = 0;
 
     for (;;) {
         refill_lanes(A, lane, alive, P, chunk_next, chunk_end, exhausted);
         const unsigned long long live = __ballot(alive);
         if (live == 0ull) break;
         casts += (unsigned long long)__popcll(live);
+        iters++;
         const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
 
         // ---- ray-side K vectors of this lane's own ray, as bf16 parts
@@ -756,9 +768,9 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             }
         }
         flush();
-        shade_lane<false, true>(A, P, alive, kind, ibest, tbest);
+        shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
     }
-    if (lane == 0 && casts != 0) atomicAdd(A.cast_counter, casts);
+    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
 }
 
 // reduce pass (what reduce_v1.glsl:66-76 was meant to be): samples are summed per pixel in sample order.
@@ -1350,7 +1362,7 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     ctx->last_was_path = true;
     ctx->rendered = true;
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
-    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 8, stream));
+    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 16, stream));
     if (npix == 0) { RT3_HIP(hipEventRecord(ctx->ev_end, stream)); return 0; }
 
     // batch size: per-sample storage of 16 B per (pixel, sample), capped
@@ -1400,7 +1412,7 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     // sphere-only scenes of <= 512 spheres: candidate filter on the matrix cores (RT3_NO_MFMA=1 keeps the VALU scan, for A/B runs)
     const bool use_mfma = !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && ctx->d_sph_frag && !getenv("RT3_NO_MFMA");
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
-    const size_t mfma_lds = (size_t)mfma_blocks * (4096 + 512) + (size_t)2 * kMQ * kMB;
+    const size_t mfma_lds = (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)2 * kMQ * kMB;
     if (use_mfma) RT3_HIP(hipFuncSetAttribute((const void*)k_trace_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
     int per_cu = 0;
     if (use_mfma) RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mfma, kMB, mfma_lds));
@@ -1467,10 +1479,11 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
     out->n_spheres = ctx->n_sph;
     out->n_faces = ctx->n_faces;
     if (ctx->last_was_path) {
-        unsigned long long casts = 0;
-        RT3_HIP(hipMemcpy(&casts, ctx->d_casts, 8, hipMemcpyDeviceToHost));
-        out->ray_casts = casts;
-        out->prim_tests = casts * ((uint64_t)ctx->n_sph + ctx->n_faces);
+        unsigned long long counters[2] = { 0, 0 };
+        RT3_HIP(hipMemcpy(counters, ctx->d_casts, 16, hipMemcpyDeviceToHost));
+        out->ray_casts = counters[0];
+        out->prim_tests = counters[0] * ((uint64_t)ctx->n_sph + ctx->n_faces);
+        out->mfma_instructions = counters[1];
     } else {
         out->ray_casts = ctx->last_samples;
         out->prim_tests = ctx->last_samples * (uint64_t)ctx->n_faces;
