@@ -67,3 +67,41 @@ def test_random_scene(renderer, seed):
     bad = got != want
     assert not bad.any(), "seed %d: %d of %d pixels differ (params %r)" % (seed, bad.sum(), bad.size, case["params"])
     assert renderer.stats().ray_casts == casts
+
+
+def filter_stress_case(seed):
+    """Sphere-only scenes of 100-512 spheres placed far from the origin and at very different scales: the matrix-core
+    candidate filter works on the expanded form |C|^2 - 2 C.o + |o|^2, whose cancellation error grows with the square of the
+    coordinates; its margin must grow with it, and the exact test must still see every true hit."""
+    rng = np.random.RandomState(1000 + seed)
+    scale = float(rng.choice([0.01, 1.0, 1.0, 50.0, 2000.0]))
+    offset = rng.choice([0.0, 0.0, 300.0, 5000.0, 60000.0]) * rng.uniform(-1, 1, 3) * scale
+    n = int(rng.choice([100, 257, 400, 484, 512]))
+    cr = np.zeros((n, 4), np.float64)
+    cr[:, :3] = rng.uniform(-6, 6, (n, 3)) * np.float64([1.0, 0.4, 1.0]) + np.float64([0, 0, -9])
+    cr[:, 3] = rng.uniform(0.05, 0.9, n) * rng.choice([1.0, 1.0, 0.05], n)
+    if rng.rand() < 0.6:
+        cr[0] = (0.0, -1000.6, -9.0, 1000.0)
+    cr[:, :3] = cr[:, :3] * scale + offset
+    cr[:, 3] *= scale
+    mats = np.zeros(n, rt3.MATERIAL)
+    mats["kind"] = rng.randint(0, 4, n)
+    mats["rgb"] = rng.uniform(0.2, 1.0, (n, 3))
+    mats["param"] = np.where(mats["kind"] == 3, 1.5, rng.uniform(0.0, 0.5, n))
+    w, h = 64, 36
+    eye = np.float64([rng.uniform(-1, 1), rng.uniform(0, 1.5), 2.0]) * scale + offset
+    at = np.float64([0.0, 0.0, -9.0]) * scale + offset
+    cam = rt3.Camera().look_at(w, h, tuple(eye), tuple(at), (0.0, 1.0, 0.0), 50.0, 1.0)
+    return dict(spheres=cr.astype(np.float32), smats=mats, cam=cam.c,
+                params=dict(width=w, height=h, spp=4, max_depth=16, seed=seed + 1, flags=1, t_min=float(0.001 * scale)))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_matrix_filter_is_conservative_far_from_the_origin(renderer, seed):
+    case = filter_stress_case(seed)
+    want, casts = oracle_render(case, threads=16)
+    got = hip_render(renderer, case)
+    bad = got != want
+    assert not bad.any(), "seed %d: %d of %d pixels differ" % (seed, bad.sum(), bad.size)
+    st = renderer.stats()
+    assert st.ray_casts == casts and st.mfma_instructions > 0          # the matrix filter really ran
