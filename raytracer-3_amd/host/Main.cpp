@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "renderer/Renderer.hpp"
+#include "sceneparser/SceneParser.hpp"
 
 using namespace RayTracer;
 
@@ -25,7 +26,7 @@ struct Options {
     uint32_t width = 800, height = 600;
     std::string scene = "builtin";
     uint32_t spp = 0, depth = 50, seed = 1, gpus = 1;
-    bool gpu_prerender = false;
+    bool gpu_prerender = false, dump_scene = false;
 };
 
 void print_usage(const char* exe) {
@@ -34,12 +35,13 @@ void print_usage(const char* exe) {
               << "\t-f,--format\tThe format of the resulting frame. Supported formats are: 'png' and 'ppm' (default: png).\n"
               << "\t-W,--width\tThe width of the resulting image, in pixels (default: 800).\n"
               << "\t-H,--height\tThe height of th resulting image, in pixels (default: 600).\n"
-              << "\t   --scene\tbuiltin | three | weekend | stress100k | cornell (default: builtin = src/Main.cpp's teddy + sphere).\n"
+              << "\t   --scene\tbuiltin | three | weekend | stress100k | cornell | <file>.scene (default: builtin = src/Main.cpp's teddy + sphere).\n"
               << "\t   --spp\tSamples per pixel; enables the path tracer (default: off = the reference's 1-ray render).\n"
               << "\t   --depth\tMaximum ray casts per path (default: 50).\n"
               << "\t   --seed\tRender seed (default: 1).\n"
               << "\t   --gpus\tNumber of GPUs to shard the frame over (default: 1).\n"
               << "\t   --gpu-prerender\tTessellate spheres on the GPU instead of the host (same arrays).\n"
+              << "\t   --dump-scene\tParse the --scene file, print its entities and exit.\n"
               << "\n\t-h,--help\tShows this help menu, then exits.\n\n";
 }
 
@@ -75,6 +77,7 @@ int parse_cli(Options& opt, int argc, const char** argv) {
 
         if (key == "-h" || key == "--help") { print_usage(argv[0]); return 0; }
         if (key == "--gpu-prerender") { opt.gpu_prerender = true; continue; }
+        if (key == "--dump-scene") { opt.dump_scene = true; continue; }
         const bool known = key == "-f" || key == "--format" || key == "-W" || key == "--width" || key == "-H" || key == "--height" ||
                            key == "--scene" || key == "--spp" || key == "--depth" || key == "--seed" || key == "--gpus";
         if (!known) {
@@ -97,7 +100,7 @@ int parse_cli(Options& opt, int argc, const char** argv) {
         else if (key == "--gpus") { if (!parse_u32(value, "gpus", "Gpus", &opt.gpus)) return -1; }
         else opt.scene = value;
     }
-    if (opt.output_path.empty()) { std::cerr << "No output path given." << std::endl; return -1; }
+    if (opt.output_path.empty() && !opt.dump_scene) { std::cerr << "No output path given." << std::endl; return -1; }
     return 1;
 }
 
@@ -117,6 +120,23 @@ int main(int argc, const char** argv) {
     Options opt;
     const int parsed = parse_cli(opt, argc, argv);
     if (parsed <= 0) return parsed;
+
+    if (opt.dump_scene) {                                            // parse a .scene file and print its entities (no GPU needed)
+        try {
+            Tools::Array<ECS::RenderEntity*> entities = SceneParser::parse_file(opt.scene);
+            for (size_t i = 0; i < entities.size(); i++) {
+                const ECS::RenderEntity* e = entities[i];
+                std::cout << ECS::entity_type_names[e->type] << " faces=" << e->pre_render_faces << " vertices=" << e->pre_render_vertices;
+                if (e->type == ECS::et_triangle) { const auto* t = static_cast<const ECS::Triangle*>(e); for (int k = 0; k < 3; k++) std::cout << " p" << k + 1 << "=(" << t->points[k].x << "," << t->points[k].y << "," << t->points[k].z << ")"; std::cout << " color=(" << t->color.x << "," << t->color.y << "," << t->color.z << ")"; }
+                if (e->type == ECS::et_sphere || e->type == ECS::et_analytic_sphere) { const auto* s = static_cast<const ECS::Sphere*>(e); std::cout << " center=(" << s->center.x << "," << s->center.y << "," << s->center.z << ") radius=" << s->radius << " grid=" << s->n_meridians << "x" << s->n_parallels << " color=(" << s->color.x << "," << s->color.y << "," << s->color.z << ")"; }
+                if (e->type == ECS::et_object) { const auto* o = static_cast<const ECS::Object*>(e); std::cout << " center=(" << o->center.x << "," << o->center.y << "," << o->center.z << ") scale=" << o->scale << " color=(" << o->color.x << "," << o->color.y << "," << o->color.z << ")"; }
+                if (e->has_material) std::cout << " material=" << e->material.kind << " param=" << e->material.param;
+                std::cout << "\n";
+                delete e;
+            }
+            return 0;
+        } catch (Fatal& e) { std::cerr << "fatal: " << e.what() << std::endl; return -1; }
+    }
 
     try {
         std::vector<int> devices;
@@ -155,11 +175,18 @@ int main(int argc, const char** argv) {
             renderer.prerender(Tools::Array<ECS::RenderEntity*>());
             renderer.set_mesh(faces, verts, mats);
             path.flags = RT3_FLAG_GAMMA2 | RT3_FLAG_BLACK_BACKGROUND;
+        } else if (opt.scene.size() > 6 && opt.scene.compare(opt.scene.size() - 6, 6, ".scene") == 0) {   // a SceneLang file
+            cam.update(opt.width, opt.height, 2.0f, aspect * 2.0f, 2.0f);
+            Tools::Array<ECS::RenderEntity*> entities = SceneParser::parse_file(opt.scene);
+            renderer.prerender(entities);
+            for (size_t i = 0; i < entities.size(); i++) delete entities[i];
+            path.flags = opt.spp ? RT3_FLAG_GAMMA2 : 0;
         } else {
             std::cerr << "Unknown scene '" << opt.scene << "'" << std::endl;
             return -1;
         }
-        if (opt.scene != "builtin" && path.spp == 0) path.spp = 16;   // the analytic scenes only exist in Mode X
+        const bool from_file = opt.scene.size() > 6 && opt.scene.compare(opt.scene.size() - 6, 6, ".scene") == 0;
+        if (opt.scene != "builtin" && !from_file && path.spp == 0) path.spp = 16;   // the analytic scenes only exist in Mode X
         renderer.configure(path);
         renderer.render(cam);
 
