@@ -639,6 +639,138 @@ __host__ __device__ inline void split3(float x, uint32_t* parts /*[3]*/) {
     parts[2] = bf16_rn(r1 - bf16_up(parts[1]));
 }
 
+// Sphere-side (A operand) fragment of one bounding sphere: out[q][hh][dword] = K elements 8 hh .. 8 hh + 7 of MFMA operand q.
+// kj = (|C|^2 - r^2) - eps (|C|^2 + r^2); a padding row uses C = 0, kj = 1e30 (c' = +1e30: never a candidate).
+__host__ __device__ inline void bound_frag_row(float cx, float cy, float cz, float kj, uint32_t out[4][2][4]) {
+    uint32_t b0[4][3], b1[5][3];                                    // [term][part]
+    split3(cx, b0[0]); split3(cy, b0[1]); split3(cz, b0[2]);
+    b0[3][0] = 0x3F80u; b0[3][1] = 0u; b0[3][2] = 0u;               // the constant 1
+    for (int t = 0; t < 3; t++) for (int p = 0; p < 3; p++) b1[t][p] = b0[t][p];
+    split3(kj, b1[3]);
+    b1[4][0] = 0x3F80u; b1[4][1] = 0u; b1[4][2] = 0u;
+    for (int q = 0; q < 4; q++)
+        for (int hh = 0; hh < 2; hh++)
+            for (int d = 0; d < 4; d++) {
+                uint32_t w = 0;
+                for (int z = 0; z < 2; z++) {
+                    const int product = q >> 1, sl = 16 * (q & 1) + 8 * hh + 2 * d + z;
+                    const int part = combo_sph_part(slot_combo(product, sl)), term = slot_term(product, sl);
+                    const uint32_t v = part == 3 ? 0u : (product == 0 ? b0[term][part] : b1[term][part]);
+                    w |= v << (16 * z);
+                }
+                out[q][hh][d] = w;
+            }
+}
+__host__ __device__ inline float filter_kj(double c2, double r2) { return (float)((c2 - r2) - (double)kFilterEps * (c2 + r2)); }
+
+// Ray-side (B operand) fragments of the 64 rays of a wave, for both half-waves of columns.
+struct RayOperands { u32x4 b[2][4]; };
+__device__ __forceinline__ void build_ray_operands(float ox, float oy, float oz, float dx, float dy, float dz, bool alive, uint32_t half,
+                                                   RayOperands& R) {
+    uint32_t ra[4][3], rb[5][3];                                    // [term][part]
+    const float od = dotf(ox, oy, oz, dx, dy, dz), oo = dotf(ox, oy, oz, ox, oy, oz);
+    split3(dx, ra[0]); split3(dy, ra[1]); split3(dz, ra[2]); split3(-od, ra[3]);
+    split3(-2.0f * ox, rb[0]); split3(-2.0f * oy, rb[1]); split3(-2.0f * oz, rb[2]);
+    rb[3][0] = 0x3F80u; rb[3][1] = 0u; rb[3][2] = 0u;               // the constant 1
+    split3(alive ? oo * (1.0f - kFilterEps) : 1e30f, rb[4]);        // a dead lane's column can never produce a candidate
+    // own[d]: dword d (K elements 2d, 2d+1) of MFMA q (0,1: h-product slots 0-15 / 16-31; 2,3: c'-product).  The B fragment
+    // of set S (rays 32S .. 32S+31 as columns): lane (S, col) needs elements 8*half .. 8*half+7 of ray 32S+col — lanes 0-31
+    // keep their elements 0-7 for set 0 and fetch the partner's 0-7 for set 1; lanes 32-63 the mirror image.
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t own[8];
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            uint32_t e[2];
+#pragma unroll
+            for (int z = 0; z < 2; z++) {
+                const int product = q >> 1, sl = 16 * (q & 1) + 2 * d + z;
+                const int part = combo_ray_part(slot_combo(product, sl)), term = slot_term(product, sl);
+                e[z] = part == 3 ? 0u : (product == 0 ? ra[term][part] : rb[term][part]);
+            }
+            own[d] = e[0] | (e[1] << 16);
+        }
+        uint32_t recv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) recv[i] = (uint32_t)__shfl_xor((int)(half ? own[i] : own[4 + i]), 32);
+        R.b[0][q] = half ? u32x4{ recv[0], recv[1], recv[2], recv[3] } : u32x4{ own[0], own[1], own[2], own[3] };
+        R.b[1][q] = half ? u32x4{ own[4], own[5], own[6], own[7] } : u32x4{ recv[0], recv[1], recv[2], recv[3] };
+    }
+}
+
+// Candidate queues: per ray two sub-queues of one-byte entries e = (row block << 4) | bit, bit = 15 - accumulator register g,
+// one written by each lane half w; row = 32 (e >> 4) + (g & 3) + 8 (g >> 2) + 4 w.  Both writers of a ray sit in the same wave.
+template <class Eval>
+__device__ __forceinline__ void mfma_flush(uint8_t* s_q, uint32_t tid, uint32_t half, uint32_t (&nq)[2], Eval&& eval) {
+    const uint32_t n_own = half ? nq[1] : nq[0];
+    const uint32_t n_oth = (uint32_t)__shfl_xor((int)(half ? nq[0] : nq[1]), 32);
+    const uint8_t* q_own = s_q + (size_t)half * kMQ * kMB + tid;
+    const uint8_t* q_oth = s_q + (size_t)half * kMQ * kMB + (tid ^ 32u);
+    auto row_of = [](uint32_t e, uint32_t w) { const uint32_t g = 15u - (e & 15u); return (e >> 4) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * w; };
+    for (uint32_t i = 0; i < n_own; i++) eval(row_of(q_own[i * kMB], half));
+    for (uint32_t i = 0; i < n_oth; i++) eval(row_of(q_oth[i * kMB], half ^ 1u));
+    nq[0] = 0; nq[1] = 0;
+}
+
+// The matrix-core scan of one LDS-resident tile of up to 16 row blocks (512 bounding spheres) against the 64 rays of the wave:
+// 8 MFMAs + 64 decode ops per row block; candidates are queued (and evaluated by `eval(row)` whenever a queue could overflow).
+template <class Eval>
+__device__ __forceinline__ void mfma_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands& R, uint8_t* s_q, uint32_t tid,
+                                               uint32_t lane, uint32_t half, uint32_t (&nq)[2], Eval&& eval) {
+    uint8_t* const q0 = s_q + tid;                                  // this lane's sub-queue of set 0; set 1 is kMQ * kMB further
+    for (uint32_t blk = 0; blk < n_blocks; blk++) {
+        const u32x4* fr = s_frag + (size_t)blk * 256 + lane;
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
+        const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
+        if (__ballot((nq[0] > 16u) || (nq[1] > 16u)) != 0ull) mfma_flush(s_q, tid, half, nq, eval);   // a block adds <= 16 entries per sub-queue
+#pragma unroll
+        for (int S = 0; S < 2; S++) {
+            const f32x16 zero = { 0 };
+            f32x16 hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[S][0]), zero, 0, 0, 0);
+            hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[S][1]), hh, 0, 0, 0);
+            f32x16 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[S][2]), zero, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[S][3]), cc, 0, 0, 0);
+            uint32_t neg = 0xFFFFFFFFu;
+#pragma unroll
+            for (int g = 0; g < 16; g++) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(fma_(hh[g], hh[g], -cc[g])), 31);
+            uint32_t m = ~neg & 0xFFFFu;                            // bit 15-g <-> accumulator register g
+            uint8_t* q = q0 + (size_t)S * kMQ * kMB + nq[S] * kMB;
+            while (m != 0) {                                        // ascending row index = descending bit
+                const uint32_t top = 31u - (uint32_t)__builtin_clz(m);
+                m ^= 1u << top;
+                *q = (uint8_t)((blk << 4) | top);
+                q += kMB;
+                nq[S]++;
+            }
+        }
+    }
+}
+
+// The reference's plane + three-edge test of one face (same operations, same order as k_trace's face evaluation); returns t or NaN.
+__device__ __forceinline__ bool face_hit(const float4* __restrict__ f, float ox, float oy, float oz, float dx, float dy, float dz,
+                                         float t_lo, float t_hi, float& t_out) {
+    const float4 n = f[0];
+    const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
+    if (nd == 0.0f) return false;
+    const float t = (n.w - dot3(n.x, n.y, n.z, ox, oy, oz)) / nd;
+    if (!(t >= t_lo && t <= t_hi)) return false;
+    const float4 p1 = f[1], p2 = f[2], p3 = f[3];
+    const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+    float ex, ey, ez, qx, qy, qz, cx, cy, cz;
+    ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
+    ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
+    ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
+    t_out = t;
+    return true;
+}
+
+// Sphere scenes of <= 512 spheres: everything the loop touches lives in LDS, waves never synchronise after the prologue.
 __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32x4* __restrict__ frags, uint32_t n_blocks) {
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;                                                   // [n_blocks][4][64]
@@ -646,7 +778,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     float4* s_mat = s_sph + (size_t)n_blocks * 32;                               // materials, kinds, 1/r: read at every hit
     float* s_invr = reinterpret_cast<float*>(s_mat + (size_t)n_blocks * 32);
     uint32_t* s_kind = reinterpret_cast<uint32_t*>(s_invr + (size_t)n_blocks * 32);
-    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_kind + (size_t)n_blocks * 32);   // [2][kMQ][kMB], entry = row block << 4 | mask bit
+    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_kind + (size_t)n_blocks * 32);   // [2][kMQ][kMB]
     const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5;
     for (uint32_t k = tid; k < n_blocks * 256; k += kMB) s_frag[k] = frags[k];
     for (uint32_t k = tid; k < n_blocks * 32; k += kMB) {
@@ -673,52 +805,14 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
         casts += (unsigned long long)__popcll(live);
         iters++;
         const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+        RayOperands R;
+        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, half, R);
 
-        // ---- ray-side K vectors of this lane's own ray, as bf16 parts
-        uint32_t ra[4][3], rb[5][3];                                // [term][part]
-        {
-            const float od = dotf(ox, oy, oz, dx, dy, dz), oo = dotf(ox, oy, oz, ox, oy, oz);
-            split3(dx, ra[0]); split3(dy, ra[1]); split3(dz, ra[2]); split3(-od, ra[3]);
-            split3(-2.0f * ox, rb[0]); split3(-2.0f * oy, rb[1]); split3(-2.0f * oz, rb[2]);
-            rb[3][0] = 0x3F80u; rb[3][1] = 0u; rb[3][2] = 0u;       // the constant 1
-            split3(alive ? oo * (1.0f - kFilterEps) : 1e30f, rb[4]);   // a dead lane's column can never produce a candidate
-        }
-        // own[q][d]: dword d (K elements 2d, 2d+1) of MFMA q (0,1: h-product slots 0-15 / 16-31; 2,3: c'-product)
-        // B fragment of set S (rays 32S .. 32S+31 as columns): lane (S, col) needs elements 8*half .. 8*half+7 of ray 32S+col.
-        u32x4 bop[2][4];
-        {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t own[8];
-#pragma unroll
-                for (int d = 0; d < 8; d++) {
-                    uint32_t e[2];
-#pragma unroll
-                    for (int z = 0; z < 2; z++) {
-                        const int product = q >> 1, sl = 16 * (q & 1) + 2 * d + z;
-                        const int part = combo_ray_part(slot_combo(product, sl)), term = slot_term(product, sl);
-                        e[z] = part == 3 ? 0u : (product == 0 ? ra[term][part] : rb[term][part]);
-                    }
-                    own[d] = e[0] | (e[1] << 16);
-                }
-                // lanes 0-31 keep their elements 0-7 for set 0 and need the partner's 0-7 for set 1; lanes 32-63 the mirror image
-                uint32_t recv[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) recv[i] = (uint32_t)__shfl_xor((int)(half ? own[i] : own[4 + i]), 32);
-                bop[0][q] = half ? u32x4{ recv[0], recv[1], recv[2], recv[3] } : u32x4{ own[0], own[1], own[2], own[3] };
-                bop[1][q] = half ? u32x4{ own[4], own[5], own[6], own[7] } : u32x4{ recv[0], recv[1], recv[2], recv[3] };
-            }
-        }
-
-        // ---- nearest hit: exact evaluation of queued candidates (ties: lower sphere index, as the sequential loop)
+        // nearest hit: exact evaluation of queued candidates (ties: lower sphere index, as the sequential loop)
         float tbest = __builtin_inff();
         uint32_t ibest = 0, kind = 0;
         uint32_t nq[2] = { 0, 0 };
-        // queue entry e = (row block << 4) | bit, bit = 15 - accumulator register g; written by lane half w:
-        // sphere index = 32 (e >> 4) + (g & 3) + 8 (g >> 2) + 4 w
-        auto eval = [&](uint32_t e, uint32_t w) {
-            const uint32_t g = 15u - (e & 15u);
-            const uint32_t j = (e >> 4) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * w;
+        auto eval = [&](uint32_t j) {
             const float4 s = s_sph[j];
             const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
             const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
@@ -730,47 +824,144 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             if (!(t > A.t_min)) t = h + sq;
             if (t > A.t_min && (t < tbest || (t == tbest && j < ibest))) { tbest = t; ibest = j; kind = 2; }
         };
-        uint8_t* const q0 = s_q + tid;                              // this lane's sub-queue of set 0; set 1 is kMQ * kMB further
-        auto flush = [&]() {                                        // wave-uniform: both writers of a ray's queues are in this wave
-            const uint32_t n_own = half ? nq[1] : nq[0];
-            const uint32_t n_oth = (uint32_t)__shfl_xor((int)(half ? nq[0] : nq[1]), 32);
-            const uint8_t* q_own = s_q + (size_t)half * kMQ * kMB + tid;
-            const uint8_t* q_oth = s_q + (size_t)half * kMQ * kMB + (tid ^ 32u);
-            for (uint32_t i = 0; i < n_own; i++) eval(q_own[i * kMB], half);
-            for (uint32_t i = 0; i < n_oth; i++) eval(q_oth[i * kMB], half ^ 1u);
-            nq[0] = 0; nq[1] = 0;
-        };
-
-        for (uint32_t blk = 0; blk < n_blocks; blk++) {
-            const u32x4* fr = s_frag + (size_t)blk * 256 + lane;
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
-            if (__ballot((nq[0] > 16u) || (nq[1] > 16u)) != 0ull) flush();     // a block adds at most 16 entries per sub-queue
-#pragma unroll
-            for (int S = 0; S < 2; S++) {
-                const f32x16 zero = { 0 };
-                f32x16 hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, bop[S][0]), zero, 0, 0, 0);
-                hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bop[S][1]), hh, 0, 0, 0);
-                f32x16 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, bop[S][2]), zero, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, bop[S][3]), cc, 0, 0, 0);
-                uint32_t neg = 0xFFFFFFFFu;
-#pragma unroll
-                for (int g = 0; g < 16; g++) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(fma_(hh[g], hh[g], -cc[g])), 31);
-                uint32_t m = ~neg & 0xFFFFu;                        // bit 15-g <-> accumulator register g
-                uint8_t* q = q0 + (size_t)S * kMQ * kMB + nq[S] * kMB;
-                while (m != 0) {                                    // ascending sphere index = descending bit
-                    const uint32_t top = 31u - (uint32_t)__builtin_clz(m);
-                    m ^= 1u << top;
-                    *q = (uint8_t)((blk << 4) | top);
-                    q += kMB;
-                    nq[S]++;
-                }
-            }
-        }
-        flush();
+        mfma_scan_tile(s_frag, n_blocks, R, s_q, tid, lane, half, nq, eval);
+        mfma_flush(s_q, tid, half, nq, eval);
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
     }
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
+}
+
+// Any scene: faces (through their bounding spheres) and spheres, streamed through LDS in tiles of 512 rows.  The 16 waves of the
+// workgroup move through the tiles together (two barriers per tile); the exact tests gather their records from global memory.
+// Ties resolve as in the sequential loops: faces before spheres, then the lower index.
+template <bool HAS_TRI, bool HAS_SPH>
+__global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
+    extern __shared__ u32x4 lds_dyn[];
+    u32x4* s_frag = lds_dyn;                                                   // [16][4][64]
+    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_frag + 16 * 256);              // [2][kMQ][kMB]
+    const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5;
+
+    Path P;
+    P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
+    P.tr = P.tg = P.tb = 0.0f; P.lr = P.lg = P.lb = 0.0f; P.slot = 0; P.base = 0; P.depth = 0;
+    bool alive = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    unsigned long long casts = 0, mfmas = 0;
+
+    for (;;) {
+        refill_lanes(A, lane, alive, P, chunk_next, chunk_end, exhausted);
+        const unsigned long long live = __ballot(alive);
+        if (!__syncthreads_or(live != 0ull ? 1 : 0)) break;                      // the workgroup ends together
+        casts += (unsigned long long)__popcll(live);
+        const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+        RayOperands R;
+        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, half, R);
+        float tbest = __builtin_inff();
+        uint32_t ibest = 0, kind = 0;
+        uint32_t nq[2] = { 0, 0 };
+
+        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& eval_row) {
+            const uint32_t total_blocks = (n_rows + 31u) / 32u;
+            for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
+                const uint32_t nb = min(16u, total_blocks - b0);
+                __syncthreads();                                                // every wave is done with the previous tile
+                for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = frags[(size_t)b0 * 256 + k];
+                __syncthreads();
+                auto eval = [&](uint32_t row) { eval_row(b0 * 32u + row); };
+                mfma_scan_tile(s_frag, nb, R, s_q, tid, lane, half, nq, eval);
+                mfma_flush(s_q, tid, half, nq, eval);
+                mfmas += nb * 8ull;
+            }
+        };
+        if (HAS_TRI)
+            pass(tri_frags, A.n_tri, [&](uint32_t j) {
+                if (j >= A.n_tri) return;
+                float t;
+                if (!face_hit(A.tri + (size_t)j * 4, ox, oy, oz, dx, dy, dz, A.t_min, tbest, t)) return;
+                if (t < tbest || j < ibest) { tbest = t; ibest = j; kind = 1; }      // t <= tbest here: equal t keeps the lower face index
+            });
+        if (HAS_SPH)
+            pass(sph_frags, A.n_sph, [&](uint32_t j) {
+                if (j >= A.n_sph) return;
+                const float4 s = A.sph[j];
+                const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+                const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+                const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+                const float disc = fma_(h, h, -c);
+                if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return;
+                const float sq = __builtin_sqrtf(disc);
+                float t = h - sq;
+                if (!(t > A.t_min)) t = h + sq;
+                if (t > A.t_min && (t < tbest || (t == tbest && kind == 2 && j < ibest))) { tbest = t; ibest = j; kind = 2; }
+            });
+        shade_lane<HAS_TRI, HAS_SPH>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
+    }
+    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, mfmas); }
+}
+
+// Mode R through the matrix-core filter (camera at the origin, as k_mode_r_fast): one thread per pixel, 1024 pixels per
+// workgroup, face bounding spheres streamed through LDS in tiles of 512; the reference's literal test runs on the candidates.
+__global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ tri, const u32x4* __restrict__ tri_frags,
+                                                    const float4* __restrict__ face_rgb, uint32_t n_faces, CamDev cam,
+                                                    uint32_t width, uint32_t height, uint32_t* __restrict__ out) {
+    extern __shared__ u32x4 lds_dyn[];
+    u32x4* s_frag = lds_dyn;
+    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_frag + 16 * 256);
+    const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5;
+    const uint32_t pixel = blockIdx.x * kMB + tid;
+    const bool valid = pixel < width * height;
+    const uint32_t x = valid ? pixel % width : 0u, y = valid ? pixel / width : 0u;
+    const float u = (float)((double)(float)x / ((double)(float)width - 1.0));
+    const float v = (float)((double)(float)(height - 1 - y) / ((double)(float)height - 1.0));
+    const float ox = cam.ox, oy = cam.oy, oz = cam.oz;              // all zero (checked by the host)
+    const float dx = ((cam.lx + u * cam.hx) + v * cam.vx) - ox;
+    const float dy = ((cam.ly + u * cam.hy) + v * cam.vy) - oy;
+    const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
+    const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));     // unit direction for the filter only
+    RayOperands R;
+    build_ray_operands(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid, half, R);
+
+    uint32_t min_i = 0;
+    float min_t = __builtin_inff();
+    uint32_t nq[2] = { 0, 0 };
+    const uint32_t total_blocks = (n_faces + 31u) / 32u;
+    for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
+        const uint32_t nb = min(16u, total_blocks - b0);
+        __syncthreads();
+        for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = tri_frags[(size_t)b0 * 256 + k];
+        __syncthreads();
+        auto eval = [&](uint32_t row) {
+            const uint32_t j = b0 * 32u + row;
+            if (j >= n_faces) return;
+            const float4* f = tri + (size_t)j * 4;
+            const float4 n = f[0];
+            const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);       // SequentialRenderer.cpp:56
+            if (nd == 0.0f) return;
+            const float t = (dot3(n.x, n.y, n.z, ox, oy, oz) + n.w) / nd;      // :70
+            if (t < 0.0f || t > min_t) return;                      // :71, with equality kept for the index rule below
+            const float4 p1 = f[1], p2 = f[2], p3 = f[3];
+            const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+            float ex, ey, ez, qx, qy, qz, cx, cy, cz;
+            ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            if (t < min_t || j < min_i) { min_i = j; min_t = t; }   // "t >= min_t rejects" of :71 == the lowest index wins ties
+        };
+        mfma_scan_tile(s_frag, nb, R, s_q, tid, lane, half, nq, eval);
+        mfma_flush(s_q, tid, half, nq, eval);
+    }
+    if (!valid) return;
+    float r, g, b;
+    if (min_t < __builtin_inff()) { const float4 c = face_rgb[min_i]; r = c.x; g = c.y; b = c.z; }
+    else sky(dx, dy, dz, r, g, b);
+    out[pixel] = pack_pixel(r, g, b);
 }
 
 // reduce pass (what reduce_v1.glsl:66-76 was meant to be): samples are summed per pixel in sample order.
@@ -879,12 +1070,22 @@ __global__ void k_prerender_sphere_faces(SphereGen s, rt3_gface* __restrict__ fa
 // p3), the bounding sphere of §5.1, the material.  Entries [n_faces, n_pad) of `bound` become never-hit records.
 __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4* __restrict__ verts, uint32_t n_faces, uint32_t n_pad,
                               uint32_t n_verts, const rt3_material* __restrict__ mats, float4* __restrict__ tri, float4* __restrict__ bound,
-                              float4* __restrict__ mat, uint32_t* __restrict__ kind, uint32_t* __restrict__ error_flag) {
+                              float4* __restrict__ mat, uint32_t* __restrict__ kind, uint32_t* __restrict__ error_flag,
+                              u32x4* __restrict__ frag, uint32_t n_frag_rows) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-    if (i >= n_faces) { bound[i] = kPadSphere; return; }
+    // matrix-filter fragments: row i of block i/32, for all four operands and both lane halves (padding rows: never candidates)
+    auto write_frag = [&](float cx, float cy, float cz, float kj) {
+        if (i >= n_frag_rows) return;
+        uint32_t fr[4][2][4];
+        bound_frag_row(cx, cy, cz, kj, fr);
+        for (int q = 0; q < 4; q++)
+            for (int hh = 0; hh < 2; hh++)
+                frag[((size_t)(i / 32) * 4 + q) * 64 + hh * 32 + (i % 32)] = u32x4{ fr[q][hh][0], fr[q][hh][1], fr[q][hh][2], fr[q][hh][3] };
+    };
+    if (i >= n_pad && i >= n_frag_rows) return;
+    if (i >= n_faces) { if (i < n_pad) bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, 1e30f); return; }
     const rt3_gface f = faces[i];
-    if (f.v1 >= n_verts || f.v2 >= n_verts || f.v3 >= n_verts) { atomicOr(error_flag, 1u); bound[i] = kPadSphere; return; }
+    if (f.v1 >= n_verts || f.v2 >= n_verts || f.v3 >= n_verts) { atomicOr(error_flag, 1u); bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, 1e30f); return; }
     const float4 p1 = verts[f.v1], p2 = verts[f.v2], p3 = verts[f.v3];
     tri[4 * (size_t)i] = make_float4(f.normal[0], f.normal[1], f.normal[2], dot3(f.normal[0], f.normal[1], f.normal[2], p1.x, p1.y, p1.z));
     tri[4 * (size_t)i + 1] = make_float4(p1.x, p1.y, p1.z, 0.0f);
@@ -905,6 +1106,11 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
     if ((double)r2f < r * r) r2f = __uint_as_float(__float_as_uint(r2f) + 1u);
     if (!(r2f >= 0.0f)) r2f = __builtin_inff();                    // NaN / inf vertices: always a candidate, the exact test decides
     bound[i] = make_float4((float)cx, (float)cy, (float)cz, r2f);
+    {
+        const float fx = (float)cx, fy = (float)cy, fz = (float)cz;
+        const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
+        write_frag(fx, fy, fz, r2f < __builtin_inff() ? filter_kj(c2, (double)r2f) : -1e30f);    // r^2 = inf: always a candidate
+    }
     if (mats) {
         const rt3_material m = mats[i];
         if (m.kind == RT3_MAT_DIELECTRIC) {                         // same packing as pack_material() on the host
@@ -930,7 +1136,7 @@ struct rt3_ctx {
 
     // mesh
     uint32_t n_faces = 0;
-    float4* d_tri = nullptr; float4* d_tri_mat = nullptr; uint32_t* d_tri_kind = nullptr; float4* d_tri_bound = nullptr;
+    float4* d_tri = nullptr; float4* d_tri_mat = nullptr; uint32_t* d_tri_kind = nullptr; float4* d_tri_bound = nullptr; u32x4* d_tri_frag = nullptr;
     // merged entity buffers on the device (GFace[] / vec4[] as the reference keeps them), filled by rt3_mesh_*
     rt3_gface* d_gfaces = nullptr; float4* d_verts = nullptr; uint32_t cap_gfaces = 0, cap_verts = 0;
     rt3_material* d_face_mats_in = nullptr; uint32_t* d_error = nullptr;
@@ -1058,37 +1264,22 @@ float4 pack_material(const rt3_material& m) {
     return make_float4(ri_f, r0f, r0b, m.param);
 }
 
-// Sphere-side operand fragments of k_trace_mfma: [row block of 32 spheres][4 MFMA operands][64 lanes] x 8 bf16.
+// Sphere-side operand fragments of the matrix filter: [row block of 32 spheres][4 MFMA operands][64 lanes] x 8 bf16.
 // Lane l holds, for sphere (l & 31) of the block, K elements 8 (l >> 5) .. +7 of the operand; padding rows can never be candidates.
 std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n) {
     const uint32_t blocks = (n + 31u) / 32u;
     std::vector<uint32_t> out((size_t)blocks * 4 * 64 * 4, 0u);
-    for (uint32_t blk = 0; blk < blocks; blk++)
-        for (uint32_t row = 0; row < 32; row++) {
-            const uint32_t j = blk * 32 + row;
-            uint32_t b0[4][3], b1[5][3];                            // [term][part]
-            if (j < n) {
-                const float* s = center_radius + 4 * (size_t)j;
-                const double c2 = (double)s[0] * s[0] + (double)s[1] * s[1] + (double)s[2] * s[2], r2 = (double)s[3] * s[3];
-                const float kj = (float)((c2 - r2) - (double)kFilterEps * (c2 + r2));
-                split3(s[0], b0[0]); split3(s[1], b0[1]); split3(s[2], b0[2]);
-                split3(s[0], b1[0]); split3(s[1], b1[1]); split3(s[2], b1[2]); split3(kj, b1[3]);
-            } else {
-                for (int t = 0; t < 3; t++) for (int p = 0; p < 3; p++) { b0[t][p] = 0; b1[t][p] = 0; }
-                split3(1e30f, b1[3]);                               // c' = +1e30: the discriminant is hugely negative
-            }
-            b0[3][0] = 0x3F80u; b0[3][1] = 0; b0[3][2] = 0;         // the constant 1
-            b1[4][0] = 0x3F80u; b1[4][1] = 0; b1[4][2] = 0;
-            for (int q = 0; q < 4; q++)
-                for (uint32_t hh = 0; hh < 2; hh++)
-                    for (int e = 0; e < 8; e++) {
-                        const int product = q >> 1, sl = 16 * (q & 1) + 8 * (int)hh + e;
-                        const int part = combo_sph_part(slot_combo(product, sl)), term = slot_term(product, sl);
-                        const uint32_t v = part == 3 ? 0u : (product == 0 ? b0[term][part] : b1[term][part]);
-                        const size_t dword = (((size_t)blk * 4 + q) * 64 + (hh * 32 + row)) * 4 + e / 2;
-                        out[dword] |= v << (16 * (e & 1));
-                    }
-        }
+    for (uint32_t j = 0; j < blocks * 32; j++) {
+        uint32_t fr[4][2][4];
+        if (j < n) {
+            const float* s = center_radius + 4 * (size_t)j;
+            const double c2 = (double)s[0] * s[0] + (double)s[1] * s[1] + (double)s[2] * s[2], r2 = (double)s[3] * s[3];
+            bound_frag_row(s[0], s[1], s[2], filter_kj(c2, r2), fr);
+        } else bound_frag_row(0.0f, 0.0f, 0.0f, 1e30f, fr);
+        for (int q = 0; q < 4; q++)
+            for (int hh = 0; hh < 2; hh++)
+                std::memcpy(&out[((((size_t)(j / 32) * 4 + q) * 64) + hh * 32 + (j % 32)) * 4], fr[q][hh], 16);
+    }
     return out;
 }
 
@@ -1150,7 +1341,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
+    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_out, ctx->d_work, ctx->d_casts };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -1226,7 +1417,7 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     if (!ctx) return RT3_E_ARG;
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
-    for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_face_mats_in })
+    for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in })
         if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
     ctx->n_faces = 0;
     if (n == 0) return 0;
@@ -1239,12 +1430,15 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     RT3_HIP(hipMalloc((void**)&ctx->d_tri_mat, (size_t)n * sizeof(float4)));
     RT3_HIP(hipMalloc((void**)&ctx->d_tri_kind, (size_t)n * sizeof(uint32_t)));
     RT3_HIP(hipMalloc((void**)&ctx->d_tri_bound, (size_t)n_pad * sizeof(float4)));
+    const uint32_t n_frag_rows = (n + 31u) / 32u * 32u;
+    RT3_HIP(hipMalloc((void**)&ctx->d_tri_frag, (size_t)n_frag_rows * 8 * sizeof(u32x4)));      // 4 operands x 2 lane halves per row
     if (face_materials) {
         RT3_HIP(hipMalloc((void**)&ctx->d_face_mats_in, (size_t)n * sizeof(rt3_material)));
         RT3_HIP(hipMemcpyAsync(ctx->d_face_mats_in, face_materials, (size_t)n * sizeof(rt3_material), hipMemcpyHostToDevice, ctx->stream));
     }
-    hipLaunchKernelGGL(k_commit_mesh, dim3((n_pad + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, ctx->d_gfaces, ctx->d_verts, n, n_pad,
-                       ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error);
+    hipLaunchKernelGGL(k_commit_mesh, dim3((n_frag_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, ctx->d_gfaces, ctx->d_verts, n, n_pad,
+                       ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
+                       ctx->d_tri_frag, n_frag_rows);
     RT3_HIP(hipGetLastError());
     uint32_t err = 0;
     RT3_HIP(hipMemcpyAsync(&err, ctx->d_error, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1290,8 +1484,7 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
         kind[i] = materials[i].kind;
     }
     int rc;
-    if ((rc = upload(ctx, &ctx->d_sph_frag, n <= kMfmaSphMax ? build_sphere_frags(center_radius, n) : std::vector<uint32_t>())))
-        return rc;
+    if ((rc = upload(ctx, &ctx->d_sph_frag, build_sphere_frags(center_radius, n)))) return rc;
     if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
         (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
         return rc;
@@ -1315,7 +1508,12 @@ int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint3
     // k_mode_r_fast needs n.o == 0 exactly (camera at the origin, as Camera::update always builds it) and finite rays;
     // any other camera takes the plain brute-force kernel, which reproduces the reference for every input.
     const bool at_origin = cam->origin[0] == 0.0f && cam->origin[1] == 0.0f && cam->origin[2] == 0.0f;
-    if (at_origin && !ctx->force_plain_mode_r)
+    if (at_origin && !ctx->force_plain_mode_r && !getenv("RT3_NO_MFMA") && ctx->n_faces > 0) {
+        const size_t lds = (size_t)16 * 4096 + (size_t)2 * kMQ * kMB;
+        RT3_HIP(hipFuncSetAttribute((const void*)k_mode_r_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mode_r_mfma, dim3((npix + kMB - 1) / kMB), dim3(kMB), lds, stream,
+                           ctx->d_tri, (const u32x4*)ctx->d_tri_frag, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
+    } else if (at_origin && !ctx->force_plain_mode_r)
         hipLaunchKernelGGL(k_mode_r_fast, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                            ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
     else
@@ -1409,14 +1607,23 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     const size_t lds_bytes = sph_lds ? (size_t)ctx->n_sph * sizeof(float4) : 0;
     const TraceKernel kernel = has_tri ? (has_sph ? (sph_lds ? k_trace<true, true, true> : k_trace<true, true, false>) : k_trace<true, false, false>)
                                        : (sph_lds ? k_trace<false, true, true> : k_trace<false, true, false>);
-    // sphere-only scenes of <= 512 spheres: candidate filter on the matrix cores (RT3_NO_MFMA=1 keeps the VALU scan, for A/B runs)
-    const bool use_mfma = !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && ctx->d_sph_frag && !getenv("RT3_NO_MFMA");
+    // candidate filter on the matrix cores (RT3_NO_MFMA=1 keeps the VALU scan, for A/B runs): the all-in-LDS kernel for sphere
+    // scenes of <= 512 spheres, the tiled kernel for everything else
+    const bool use_mfma = !getenv("RT3_NO_MFMA");
+    const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax;
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
-    const size_t mfma_lds = (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)2 * kMQ * kMB;
-    if (use_mfma) RT3_HIP(hipFuncSetAttribute((const void*)k_trace_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
+    const size_t mfma_lds = mfma_single ? (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)2 * kMQ * kMB
+                                        : (size_t)16 * 4096 + (size_t)2 * kMQ * kMB;
+    using TiledKernel = void (*)(const TraceArgs, const u32x4*, const u32x4*);
+    const TiledKernel tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true> : k_trace_mfma_tiled<true, false>) : k_trace_mfma_tiled<false, true>;
     int per_cu = 0;
-    if (use_mfma) RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mfma, kMB, mfma_lds));
-    else RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes));
+    if (mfma_single) {
+        RT3_HIP(hipFuncSetAttribute((const void*)k_trace_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
+        RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mfma, kMB, mfma_lds));
+    } else if (use_mfma) {
+        RT3_HIP(hipFuncSetAttribute((const void*)tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
+        RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tiled, kMB, mfma_lds));
+    } else RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes));
     if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_trace does not fit on a CU");
     per_cu = std::min(per_cu, 8);
 
@@ -1431,7 +1638,8 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
         if ((rc = take_event_pair(ctx, &a, &b))) return rc;
         RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
         RT3_HIP(hipEventRecord(a, stream));
-        if (use_mfma) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), mfma_lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
+        if (mfma_single) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), mfma_lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
+        else if (use_mfma) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kMB), mfma_lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag);
         else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipEventRecord(b, stream));
