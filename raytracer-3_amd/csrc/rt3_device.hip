@@ -711,18 +711,45 @@ __device__ __forceinline__ void mfma_flush(uint8_t* s_q, uint32_t tid, uint32_t 
     for (uint32_t i = 0; i < n_oth; i++) eval(row_of(q_oth[i * kMB], half ^ 1u));
     nq[0] = 0; nq[1] = 0;
 }
+// Same, for exact tests that gather from global memory: `fetch(row)` (the first 16 bytes of the record) is issued one
+// candidate ahead of `eval(row, record)`.
+template <class Fetch, class Eval>
+__device__ __forceinline__ void mfma_flush_prefetch(uint8_t* s_q, uint32_t tid, uint32_t half, uint32_t (&nq)[2], Fetch&& fetch, Eval&& eval) {
+    const uint32_t n_own = half ? nq[1] : nq[0];
+    const uint32_t n_oth = (uint32_t)__shfl_xor((int)(half ? nq[0] : nq[1]), 32);
+    const uint32_t n = n_own + n_oth;
+    const uint8_t* q_own = s_q + (size_t)half * kMQ * kMB + tid;
+    const uint8_t* q_oth = s_q + (size_t)half * kMQ * kMB + (tid ^ 32u);
+    auto entry_row = [&](uint32_t i) {
+        const bool own = i < n_own;
+        const uint32_t e = own ? q_own[i * kMB] : q_oth[(i - n_own) * kMB];
+        const uint32_t g = 15u - (e & 15u);
+        return (e >> 4) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * (own ? half : half ^ 1u);
+    };
+    if (n != 0) {
+        uint32_t row = entry_row(0);
+        float4 rec = fetch(row);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t rown = i + 1 < n ? entry_row(i + 1) : row;
+            const float4 recn = i + 1 < n ? fetch(rown) : rec;
+            eval(row, rec);
+            row = rown; rec = recn;
+        }
+    }
+    nq[0] = 0; nq[1] = 0;
+}
 
 // The matrix-core scan of one LDS-resident tile of up to 16 row blocks (512 bounding spheres) against the 64 rays of the wave:
-// 8 MFMAs + 64 decode ops per row block; candidates are queued (and evaluated by `eval(row)` whenever a queue could overflow).
-template <class Eval>
+// 8 MFMAs + 64 decode ops per row block; candidates are queued (`flush()` evaluates them whenever a queue could overflow).
+template <class Flush>
 __device__ __forceinline__ void mfma_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands& R, uint8_t* s_q, uint32_t tid,
-                                               uint32_t lane, uint32_t half, uint32_t (&nq)[2], Eval&& eval) {
+                                               uint32_t lane, uint32_t half, uint32_t (&nq)[2], Flush&& flush) {
     uint8_t* const q0 = s_q + tid;                                  // this lane's sub-queue of set 0; set 1 is kMQ * kMB further
     for (uint32_t blk = 0; blk < n_blocks; blk++) {
         const u32x4* fr = s_frag + (size_t)blk * 256 + lane;
         const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
         const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
-        if (__ballot((nq[0] > 16u) || (nq[1] > 16u)) != 0ull) mfma_flush(s_q, tid, half, nq, eval);   // a block adds <= 16 entries per sub-queue
+        if (__ballot((nq[0] > 16u) || (nq[1] > 16u)) != 0ull) flush();     // a block adds <= 16 entries per sub-queue
 #pragma unroll
         for (int S = 0; S < 2; S++) {
             const f32x16 zero = { 0 };
@@ -747,9 +774,8 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* s_frag, uint32_t n_b
 }
 
 // The reference's plane + three-edge test of one face (same operations, same order as k_trace's face evaluation); returns t or NaN.
-__device__ __forceinline__ bool face_hit(const float4* __restrict__ f, float ox, float oy, float oz, float dx, float dy, float dz,
+__device__ __forceinline__ bool face_hit(const float4 n, const float4* __restrict__ f, float ox, float oy, float oz, float dx, float dy, float dz,
                                          float t_lo, float t_hi, float& t_out) {
-    const float4 n = f[0];
     const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
     if (nd == 0.0f) return false;
     const float t = (n.w - dot3(n.x, n.y, n.z, ox, oy, oz)) / nd;
@@ -824,8 +850,9 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             if (!(t > A.t_min)) t = h + sq;
             if (t > A.t_min && (t < tbest || (t == tbest && j < ibest))) { tbest = t; ibest = j; kind = 2; }
         };
-        mfma_scan_tile(s_frag, n_blocks, R, s_q, tid, lane, half, nq, eval);
-        mfma_flush(s_q, tid, half, nq, eval);
+        auto flush = [&]() { mfma_flush(s_q, tid, half, nq, eval); };
+        mfma_scan_tile(s_frag, n_blocks, R, s_q, tid, lane, half, nq, flush);
+        flush();
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
     }
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
@@ -861,30 +888,32 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
         uint32_t ibest = 0, kind = 0;
         uint32_t nq[2] = { 0, 0 };
 
-        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& eval_row) {
+        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& fetch_row, auto&& eval_row) {
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
             for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
                 const uint32_t nb = min(16u, total_blocks - b0);
                 __syncthreads();                                                // every wave is done with the previous tile
                 for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = frags[(size_t)b0 * 256 + k];
                 __syncthreads();
-                auto eval = [&](uint32_t row) { eval_row(b0 * 32u + row); };
-                mfma_scan_tile(s_frag, nb, R, s_q, tid, lane, half, nq, eval);
-                mfma_flush(s_q, tid, half, nq, eval);
+                auto flush = [&]() {
+                    mfma_flush_prefetch(s_q, tid, half, nq, [&](uint32_t row) { return fetch_row(b0 * 32u + row); },
+                                        [&](uint32_t row, const float4 rec) { eval_row(b0 * 32u + row, rec); });
+                };
+                mfma_scan_tile(s_frag, nb, R, s_q, tid, lane, half, nq, flush);
+                flush();
                 mfmas += nb * 8ull;
             }
         };
         if (HAS_TRI)
-            pass(tri_frags, A.n_tri, [&](uint32_t j) {
+            pass(tri_frags, A.n_tri, [&](uint32_t j) { return A.tri[(size_t)min(j, A.n_tri - 1u) * 4]; }, [&](uint32_t j, const float4 n) {
                 if (j >= A.n_tri) return;
                 float t;
-                if (!face_hit(A.tri + (size_t)j * 4, ox, oy, oz, dx, dy, dz, A.t_min, tbest, t)) return;
+                if (!face_hit(n, A.tri + (size_t)j * 4, ox, oy, oz, dx, dy, dz, A.t_min, tbest, t)) return;
                 if (t < tbest || j < ibest) { tbest = t; ibest = j; kind = 1; }      // t <= tbest here: equal t keeps the lower face index
             });
         if (HAS_SPH)
-            pass(sph_frags, A.n_sph, [&](uint32_t j) {
+            pass(sph_frags, A.n_sph, [&](uint32_t j) { return A.sph[min(j, A.n_sph - 1u)]; }, [&](uint32_t j, const float4 s) {
                 if (j >= A.n_sph) return;
-                const float4 s = A.sph[j];
                 const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
                 const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
                 const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
@@ -931,11 +960,10 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
         __syncthreads();
         for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = tri_frags[(size_t)b0 * 256 + k];
         __syncthreads();
-        auto eval = [&](uint32_t row) {
+        auto eval = [&](uint32_t row, const float4 n) {
             const uint32_t j = b0 * 32u + row;
             if (j >= n_faces) return;
             const float4* f = tri + (size_t)j * 4;
-            const float4 n = f[0];
             const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);       // SequentialRenderer.cpp:56
             if (nd == 0.0f) return;
             const float t = (dot3(n.x, n.y, n.z, ox, oy, oz) + n.w) / nd;      // :70
@@ -954,8 +982,11 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
             if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
             if (t < min_t || j < min_i) { min_i = j; min_t = t; }   // "t >= min_t rejects" of :71 == the lowest index wins ties
         };
-        mfma_scan_tile(s_frag, nb, R, s_q, tid, lane, half, nq, eval);
-        mfma_flush(s_q, tid, half, nq, eval);
+        auto flush = [&]() {
+            mfma_flush_prefetch(s_q, tid, half, nq, [&](uint32_t row) { return tri[(size_t)min(b0 * 32u + row, n_faces - 1u) * 4]; }, eval);
+        };
+        mfma_scan_tile(s_frag, nb, R, s_q, tid, lane, half, nq, flush);
+        flush();
     }
     if (!valid) return;
     float r, g, b;
