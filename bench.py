@@ -76,12 +76,20 @@ def cpu_baseline(rt3, cr, mats, cam, budget_s):
     # calibrate on a small frame, then size the timed sample to ~budget_s
     probe = run(240, 135, 2, cores)
     total = max(240 * 135 * 2, int(probe * 1e6 * budget_s))
-    spp = 4
-    h = max(54, int((total / spp / (16.0 / 9.0)) ** 0.5))
-    w = h * 16 // 9
+    # the workload's own frame with the first `spp` of its 512 samples per pixel (not a perfect square, like 512, so the
+    # same un-stratified sampling law applies); a slow host falls back to a smaller 16:9 frame at 2 spp
+    w, h = WIDTH, HEIGHT
+    spp = int(total // (w * h))
+    if spp < 2:
+        spp = 2
+        h = max(54, int((total / spp / (16.0 / 9.0)) ** 0.5))
+        w = h * 16 // 9
+    elif int(spp ** 0.5) ** 2 == spp:
+        spp += 1
+    spp = min(spp, SPP)
     rate_n = run(w, h, spp, cores)
     sample = "%dx%dx%dspp depth %d (same scene/camera/seed), %d threads" % (w, h, spp, DEPTH, cores)
-    rate_1 = run(max(32, w // 4), max(18, h // 4), spp, 1)
+    rate_1 = run(max(32, w // 4), max(18, h // 4), max(2, spp // 4), 1)
     return {"value": round(rate_n, 4), "unit": "Msamples/s", "cores": cores, "kind": "port", "sample": sample,
             "value_1thread": round(rate_1, 4)}
 

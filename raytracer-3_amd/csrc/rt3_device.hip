@@ -596,35 +596,42 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Mode X, sphere scenes that fit one LDS image: the candidate filter on the MATRIX cores
+// The candidate filter on the MATRIX cores
 // ------------------------------------------------------------------------------------------------------
-// The discriminant sign of every (sphere, ray) pair is a dense contraction:
-//     h_ij  = C_j.d_i - o_i.d_i                                   = sum_t a_t  b_t ,  a = (dx,dy,dz,-o.d),            b = (Cx,Cy,Cz,1)
-//     c'_ij = |C_j - o_i|^2 - r_j^2 - margin_ij                   = sum_t a'_t b'_t,  a' = (-2ox,-2oy,-2oz,1,|o|^2(1-eps)), b' = (Cx,Cy,Cz,K_j,1)
-//     K_j   = (|C_j|^2 - r_j^2) - eps (|C_j|^2 + r_j^2),   margin_ij = eps (|C_j|^2 + r_j^2 + |o_i|^2),   candidate iff h^2 - c' >= 0
-// It runs on v_mfma_f32_32x32x16_bf16 with every f32 factor split into three bf16 parts (x = H + M + L) and the six leading
-// cross products (HH, HM, MH, HL, LH, MM) laid out along K: 4 x 6 = 24 of 32 K-slots for h, 5 x 6 = 30 of 32 for c' — f32-level
-// accuracy at 1/4 of the cycles the 10 VALU instructions per pair cost.  The expanded form cancels catastrophically and is
-// therefore used ONLY as a conservative filter: eps = 2e-5 covers its error (<= ~2e-6 (|C|+|o|)^2) several times over, and the
-// surviving pairs go through the same exact f32 evaluation as in k_trace, so images stay bit-identical.
-// A = spheres (rows), B = rays (columns): lane l then holds, for ray (l & 31) of the current half-wave, 16 results in its
-// accumulator registers (rows (g&3) + 8(g>>2) + 4(l>>5)), turns their signs into a 16-bit mask with 2 VALU ops per pair and
-// queues the candidates for the ray's own lane.
-constexpr int      kMB        = 1024;      // threads per workgroup of k_trace_mfma (one workgroup per CU, 4 waves per SIMD)
-constexpr int      kMQ        = 32;        // one-byte slots per candidate sub-queue (two writers per ray); flushed above 16
+// For a unit direction d the discriminant of every (sphere, ray) pair is ONE dense contraction of 11 bilinear terms:
+//     disc_ij = (d_i.(C_j - o_i))^2 - |C_j - o_i|^2 + r_j^2
+//             = sum_{a<=b} (d_a d_b [x2 if a != b]) (C_a C_b)  +  sum_a (2 o_a - 2 (o.d) d_a) C_a  +  1 K_j  +  E_i 1
+//     K_j = (r_j^2 - |C_j|^2) + eps (|C_j|^2 + r_j^2),    E_i = (o.d)^2 - |o|^2 (1 - eps)
+// i.e. disc + margin with margin_ij = eps (|C_j|^2 + r_j^2 + |o_i|^2).  It runs on v_mfma_f32_32x32x16_bf16 with every f32 factor
+// split into three bf16 parts (x = H + M + L) and the six leading cross products (HH, HM, MH, HL, LH, MM) laid out along K:
+// 9 x 6 + 3 + 3 = 60 of the 64 K-slots of four chained MFMAs, so the accumulator holds the margin-inflated discriminant itself and
+// its SIGN BIT is the candidate flag — one v_alignbit per pair on the vector ALU instead of the 10 instructions of the scalar test.
+// The expanded form cancels catastrophically and is therefore used ONLY as a conservative filter: eps = 2e-5 covers its error
+// (measured <= 0.05 eps (|C|^2 + r^2 + |o|^2) in tools/filter_model.py's pessimistic model) twenty times over, and the surviving
+// pairs go through the same exact f32 evaluation as in k_trace, so images stay bit-identical.
+// A = spheres (rows), B = rays (columns): lane l holds, for ray (l & 31) of the current column set, 16 results in its accumulator
+// registers (rows (g&3) + 8(g>>2) + 4(l>>5)).  Spheres are assigned to rows so that accumulator register g of lane half w is sphere
+// 16 w + 15 - g of the row block: after one v_permlane32_swap every lane owns the 32-bit candidate word of ITS OWN ray for the
+// block, bit b <-> sphere 32 blk + b, which it parks in a lane-private LDS column until the exact tests run.
+constexpr int      kMB        = 1024;      // threads per workgroup of the matrix-filter kernels (one workgroup per CU, 4 waves per SIMD)
 constexpr uint32_t kMfmaSphMax = 512;      // 16 row blocks x 4 operand fragments x 1 KiB = 64 KiB of LDS
+constexpr uint32_t kBitmapBytes = 16 * kMB * 4;   // candidate words: [16 row blocks][kMB lanes]
 constexpr float    kFilterEps = 2e-5f;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// K-slot tables, shared by the host (sphere fragments) and the device (ray fragments).  part: 0 = H, 1 = M, 2 = L, 3 = zero.
-__host__ __device__ constexpr int combo_ray_part(int c) { return c == 0 ? 0 : c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 0 : c == 4 ? 2 : c == 5 ? 1 : 3; }
-__host__ __device__ constexpr int combo_sph_part(int c) { return c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 0 : c == 3 ? 2 : c == 4 ? 0 : c == 5 ? 1 : 3; }
-// product 0 (h): slot = 4 combo + term;  product 1 (c'): slot = 5 combo + term (30, 31 unused)
-__host__ __device__ constexpr int slot_combo(int product, int s) { return product == 0 ? s / 4 : (s < 30 ? s / 5 : 7); }
-__host__ __device__ constexpr int slot_term(int product, int s) { return product == 0 ? s % 4 : s % 5; }
+// K-slot table, shared by the host (sphere fragments) and the device (ray fragments).  Slot s of the 64: s < 54 is term s % 9 in
+// cross product s / 9; 54..56 are the parts of K_j against the ray's constant 1; 57..59 the parts of E_i against the sphere's
+// constant 1; 60..63 are empty.  part: 0 = H, 1 = M, 2 = L, 3 = zero.
+__host__ __device__ constexpr int combo_ray_part(int c) { return c == 0 ? 0 : c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 0 : c == 4 ? 2 : 1; }
+__host__ __device__ constexpr int combo_sph_part(int c) { return c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 0 : c == 3 ? 2 : c == 4 ? 0 : 1; }
+__host__ __device__ constexpr int slot_term(int s) { return s < 54 ? s % 9 : s < 57 ? 9 : s < 60 ? 10 : 11; }
+__host__ __device__ constexpr int slot_ray_part(int s) { return s < 54 ? combo_ray_part(s / 9) : s < 57 ? 0 : s < 60 ? s - 57 : 3; }
+__host__ __device__ constexpr int slot_sph_part(int s) { return s < 54 ? combo_sph_part(s / 9) : s < 57 ? s - 54 : s < 60 ? 0 : 3; }
+// row of the A operand that holds sphere b (0..31) of a row block
+__host__ __device__ constexpr uint32_t frag_row_of(uint32_t b) { return ((15u - (b & 15u)) & 3u) + 8u * ((15u - (b & 15u)) >> 2) + 4u * (b >> 4); }
 
 __host__ __device__ inline uint32_t bf16_rn(float x) {            // round to nearest even, finite inputs
     uint32_t u = __builtin_bit_cast(uint32_t, x);
@@ -640,42 +647,43 @@ __host__ __device__ inline void split3(float x, uint32_t* parts /*[3]*/) {
 }
 
 // Sphere-side (A operand) fragment of one bounding sphere: out[q][hh][dword] = K elements 8 hh .. 8 hh + 7 of MFMA operand q.
-// kj = (|C|^2 - r^2) - eps (|C|^2 + r^2); a padding row uses C = 0, kj = 1e30 (c' = +1e30: never a candidate).
+// kj = filter_kj(|C|^2, r^2); a padding row uses C = 0, kj = -1e30 (never a candidate), an unbounded one kj = +1e30 (always).
 __host__ __device__ inline void bound_frag_row(float cx, float cy, float cz, float kj, uint32_t out[4][2][4]) {
-    uint32_t b0[4][3], b1[5][3];                                    // [term][part]
-    split3(cx, b0[0]); split3(cy, b0[1]); split3(cz, b0[2]);
-    b0[3][0] = 0x3F80u; b0[3][1] = 0u; b0[3][2] = 0u;               // the constant 1
-    for (int t = 0; t < 3; t++) for (int p = 0; p < 3; p++) b1[t][p] = b0[t][p];
-    split3(kj, b1[3]);
-    b1[4][0] = 0x3F80u; b1[4][1] = 0u; b1[4][2] = 0u;
+    uint32_t f[11][3];                                              // [term][part]
+    const double x = cx, y = cy, z = cz;
+    split3((float)(x * x), f[0]); split3((float)(y * y), f[1]); split3((float)(z * z), f[2]);
+    split3((float)(x * y), f[3]); split3((float)(x * z), f[4]); split3((float)(y * z), f[5]);
+    split3(cx, f[6]); split3(cy, f[7]); split3(cz, f[8]);
+    split3(kj, f[9]);
+    f[10][0] = 0x3F80u; f[10][1] = 0u; f[10][2] = 0u;               // the constant 1
     for (int q = 0; q < 4; q++)
         for (int hh = 0; hh < 2; hh++)
             for (int d = 0; d < 4; d++) {
                 uint32_t w = 0;
-                for (int z = 0; z < 2; z++) {
-                    const int product = q >> 1, sl = 16 * (q & 1) + 8 * hh + 2 * d + z;
-                    const int part = combo_sph_part(slot_combo(product, sl)), term = slot_term(product, sl);
-                    const uint32_t v = part == 3 ? 0u : (product == 0 ? b0[term][part] : b1[term][part]);
-                    w |= v << (16 * z);
+                for (int e = 0; e < 2; e++) {
+                    const int sl = 16 * q + 8 * hh + 2 * d + e;
+                    const int part = slot_sph_part(sl), term = slot_term(sl);
+                    w |= (part == 3 || term == 11 ? 0u : f[term][part]) << (16 * e);
                 }
                 out[q][hh][d] = w;
             }
 }
-__host__ __device__ inline float filter_kj(double c2, double r2) { return (float)((c2 - r2) - (double)kFilterEps * (c2 + r2)); }
+__host__ __device__ inline float filter_kj(double c2, double r2) { return (float)((r2 - c2) + (double)kFilterEps * (c2 + r2)); }
+constexpr float kNeverCandidate = -1e30f, kAlwaysCandidate = 1e30f;
 
-// Ray-side (B operand) fragments of the 64 rays of a wave, for both half-waves of columns.
+// Ray-side (B operand) fragments of the 64 rays of a wave, for both column sets (rays 0..31 / 32..63).
 struct RayOperands { u32x4 b[2][4]; };
-__device__ __forceinline__ void build_ray_operands(float ox, float oy, float oz, float dx, float dy, float dz, bool alive, uint32_t half,
-                                                   RayOperands& R) {
-    uint32_t ra[4][3], rb[5][3];                                    // [term][part]
+__device__ __forceinline__ void build_ray_operands(float ox, float oy, float oz, float dx, float dy, float dz, bool alive, RayOperands& R) {
+    uint32_t f[11][3];                                              // [term][part]
     const float od = dotf(ox, oy, oz, dx, dy, dz), oo = dotf(ox, oy, oz, ox, oy, oz);
-    split3(dx, ra[0]); split3(dy, ra[1]); split3(dz, ra[2]); split3(-od, ra[3]);
-    split3(-2.0f * ox, rb[0]); split3(-2.0f * oy, rb[1]); split3(-2.0f * oz, rb[2]);
-    rb[3][0] = 0x3F80u; rb[3][1] = 0u; rb[3][2] = 0u;               // the constant 1
-    split3(alive ? oo * (1.0f - kFilterEps) : 1e30f, rb[4]);        // a dead lane's column can never produce a candidate
-    // own[d]: dword d (K elements 2d, 2d+1) of MFMA q (0,1: h-product slots 0-15 / 16-31; 2,3: c'-product).  The B fragment
-    // of set S (rays 32S .. 32S+31 as columns): lane (S, col) needs elements 8*half .. 8*half+7 of ray 32S+col — lanes 0-31
-    // keep their elements 0-7 for set 0 and fetch the partner's 0-7 for set 1; lanes 32-63 the mirror image.
+    split3(dx * dx, f[0]); split3(dy * dy, f[1]); split3(dz * dz, f[2]);
+    split3(2.0f * dx * dy, f[3]); split3(2.0f * dx * dz, f[4]); split3(2.0f * dy * dz, f[5]);
+    split3(2.0f * (ox - od * dx), f[6]); split3(2.0f * (oy - od * dy), f[7]); split3(2.0f * (oz - od * dz), f[8]);
+    f[9][0] = 0x3F80u; f[9][1] = 0u; f[9][2] = 0u;                  // the constant 1
+    split3(alive ? od * od - oo * (1.0f - kFilterEps) : -3e30f, f[10]);   // a dead lane's column can never produce a candidate
+    // own[d]: dword d (K elements 2d, 2d+1 of the operand's 16).  The B fragment of column set S: lane (w, col) supplies elements
+    // 8 w .. 8 w + 7 of ray 32 S + col — lanes 0-31 keep their elements 0-7 for set 0 and need their partner's 0-7 for set 1; lanes
+    // 32-63 the mirror image: exactly one v_permlane32_swap per dword pair (x's upper half <-> y's lower half).
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         uint32_t own[8];
@@ -684,92 +692,88 @@ __device__ __forceinline__ void build_ray_operands(float ox, float oy, float oz,
             uint32_t e[2];
 #pragma unroll
             for (int z = 0; z < 2; z++) {
-                const int product = q >> 1, sl = 16 * (q & 1) + 2 * d + z;
-                const int part = combo_ray_part(slot_combo(product, sl)), term = slot_term(product, sl);
-                e[z] = part == 3 ? 0u : (product == 0 ? ra[term][part] : rb[term][part]);
+                const int sl = 16 * q + 2 * d + z;
+                const int part = slot_ray_part(sl), term = slot_term(sl);
+                e[z] = (part == 3 || term == 11) ? 0u : f[term][part];
             }
             own[d] = e[0] | (e[1] << 16);
         }
-        uint32_t recv[4];
+        uint32_t s0[4], s1[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) recv[i] = (uint32_t)__shfl_xor((int)(half ? own[i] : own[4 + i]), 32);
-        R.b[0][q] = half ? u32x4{ recv[0], recv[1], recv[2], recv[3] } : u32x4{ own[0], own[1], own[2], own[3] };
-        R.b[1][q] = half ? u32x4{ own[4], own[5], own[6], own[7] } : u32x4{ recv[0], recv[1], recv[2], recv[3] };
-    }
-}
-
-// Candidate queues: per ray two sub-queues of one-byte entries e = (row block << 4) | bit, bit = 15 - accumulator register g,
-// one written by each lane half w; row = 32 (e >> 4) + (g & 3) + 8 (g >> 2) + 4 w.  Both writers of a ray sit in the same wave.
-template <class Eval>
-__device__ __forceinline__ void mfma_flush(uint8_t* s_q, uint32_t tid, uint32_t half, uint32_t (&nq)[2], Eval&& eval) {
-    const uint32_t n_own = half ? nq[1] : nq[0];
-    const uint32_t n_oth = (uint32_t)__shfl_xor((int)(half ? nq[0] : nq[1]), 32);
-    const uint8_t* q_own = s_q + (size_t)half * kMQ * kMB + tid;
-    const uint8_t* q_oth = s_q + (size_t)half * kMQ * kMB + (tid ^ 32u);
-    auto row_of = [](uint32_t e, uint32_t w) { const uint32_t g = 15u - (e & 15u); return (e >> 4) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * w; };
-    for (uint32_t i = 0; i < n_own; i++) eval(row_of(q_own[i * kMB], half));
-    for (uint32_t i = 0; i < n_oth; i++) eval(row_of(q_oth[i * kMB], half ^ 1u));
-    nq[0] = 0; nq[1] = 0;
-}
-// Same, for exact tests that gather from global memory: `fetch(row)` (the first 16 bytes of the record) is issued one
-// candidate ahead of `eval(row, record)`.
-template <class Fetch, class Eval>
-__device__ __forceinline__ void mfma_flush_prefetch(uint8_t* s_q, uint32_t tid, uint32_t half, uint32_t (&nq)[2], Fetch&& fetch, Eval&& eval) {
-    const uint32_t n_own = half ? nq[1] : nq[0];
-    const uint32_t n_oth = (uint32_t)__shfl_xor((int)(half ? nq[0] : nq[1]), 32);
-    const uint32_t n = n_own + n_oth;
-    const uint8_t* q_own = s_q + (size_t)half * kMQ * kMB + tid;
-    const uint8_t* q_oth = s_q + (size_t)half * kMQ * kMB + (tid ^ 32u);
-    auto entry_row = [&](uint32_t i) {
-        const bool own = i < n_own;
-        const uint32_t e = own ? q_own[i * kMB] : q_oth[(i - n_own) * kMB];
-        const uint32_t g = 15u - (e & 15u);
-        return (e >> 4) * 32u + (g & 3u) + 8u * (g >> 2) + 4u * (own ? half : half ^ 1u);
-    };
-    if (n != 0) {
-        uint32_t row = entry_row(0);
-        float4 rec = fetch(row);
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t rown = i + 1 < n ? entry_row(i + 1) : row;
-            const float4 recn = i + 1 < n ? fetch(rown) : rec;
-            eval(row, rec);
-            row = rown; rec = recn;
+        for (int i = 0; i < 4; i++) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(own[i], own[4 + i], false, false);
+            s0[i] = sw[0]; s1[i] = sw[1];
         }
+        R.b[0][q] = u32x4{ s0[0], s0[1], s0[2], s0[3] };
+        R.b[1][q] = u32x4{ s1[0], s1[1], s1[2], s1[3] };
     }
-    nq[0] = 0; nq[1] = 0;
 }
 
 // The matrix-core scan of one LDS-resident tile of up to 16 row blocks (512 bounding spheres) against the 64 rays of the wave:
-// 8 MFMAs + 64 decode ops per row block; candidates are queued (`flush()` evaluates them whenever a queue could overflow).
-template <class Flush>
-__device__ __forceinline__ void mfma_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands& R, uint8_t* s_q, uint32_t tid,
-                                               uint32_t lane, uint32_t half, uint32_t (&nq)[2], Flush&& flush) {
-    uint8_t* const q0 = s_q + tid;                                  // this lane's sub-queue of set 0; set 1 is kMQ * kMB further
+// per row block 8 MFMAs, 32 v_alignbit and one exchange.  Candidate word `blk` of this lane's ray goes to bm[blk * kMB] (bit b
+// CLEAR <-> sphere 32 blk + b is a candidate); the return value has bit blk set when that word holds any candidate.
+__device__ __forceinline__ uint32_t mfma_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands& R, uint32_t* bm, uint32_t lane) {
+    uint32_t nz = 0;
     for (uint32_t blk = 0; blk < n_blocks; blk++) {
         const u32x4* fr = s_frag + (size_t)blk * 256 + lane;
         const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
         const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
-        if (__ballot((nq[0] > 16u) || (nq[1] > 16u)) != 0ull) flush();     // a block adds <= 16 entries per sub-queue
+        const f32x16 zero = { 0 };
+        f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[0][0]), zero, 0, 0, 0);
+        f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[1][0]), zero, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[0][1]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[1][1]), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[0][2]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[1][2]), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[0][3]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[1][3]), d1, 0, 0, 0);
+        uint32_t n0 = 0xFFFFFFFFu, n1 = 0xFFFFFFFFu;               // sign bits: register g -> bit 15 - g
 #pragma unroll
-        for (int S = 0; S < 2; S++) {
-            const f32x16 zero = { 0 };
-            f32x16 hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[S][0]), zero, 0, 0, 0);
-            hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[S][1]), hh, 0, 0, 0);
-            f32x16 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[S][2]), zero, 0, 0, 0);
-            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[S][3]), cc, 0, 0, 0);
-            uint32_t neg = 0xFFFFFFFFu;
+        for (int g = 0; g < 16; g++) n0 = __builtin_amdgcn_alignbit(n0, __float_as_uint(d0[g]), 31);
 #pragma unroll
-            for (int g = 0; g < 16; g++) neg = __builtin_amdgcn_alignbit(neg, __float_as_uint(fma_(hh[g], hh[g], -cc[g])), 31);
-            uint32_t m = ~neg & 0xFFFFu;                            // bit 15-g <-> accumulator register g
-            uint8_t* q = q0 + (size_t)S * kMQ * kMB + nq[S] * kMB;
-            while (m != 0) {                                        // ascending row index = descending bit
-                const uint32_t top = 31u - (uint32_t)__builtin_clz(m);
-                m ^= 1u << top;
-                *q = (uint8_t)((blk << 4) | top);
-                q += kMB;
-                nq[S]++;
-            }
-        }
+        for (int g = 0; g < 16; g++) n1 = __builtin_amdgcn_alignbit(n1, __float_as_uint(d1[g]), 31);
+        // lower lanes: own set-0 signs (rows of half 0) + the partner's set-0 signs (rows of half 1); upper lanes: set 1
+        const auto sw = __builtin_amdgcn_permlane32_swap(n0, n1, false, false);
+        const uint32_t w = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);
+        bm[blk * kMB] = w;
+        nz |= w != 0xFFFFFFFFu ? 1u << blk : 0u;
+    }
+    return nz;
+}
+
+// Exact tests of the parked candidates of this lane's ray, in ascending sphere order.
+struct CandIter { uint32_t nz, bits, blk; };
+__device__ __forceinline__ bool cand_next(CandIter& it, const uint32_t* bm, uint32_t& row) {
+    if (it.bits == 0u) {
+        if (it.nz == 0u) return false;
+        it.blk = (uint32_t)__builtin_ctz(it.nz);
+        it.nz &= it.nz - 1u;
+        it.bits = ~bm[it.blk * kMB];                                // non-zero: the scan set this word's nz bit
+    }
+    row = it.blk * 32u + (uint32_t)__builtin_ctz(it.bits);
+    it.bits &= it.bits - 1u;
+    return true;
+}
+template <class Eval>
+__device__ __forceinline__ void mfma_flush(uint32_t nz, const uint32_t* bm, Eval&& eval) {
+    CandIter it = { nz, 0u, 0u };
+    uint32_t row;
+    while (cand_next(it, bm, row)) eval(row);
+}
+// Same, for exact tests that gather from global memory: `fetch(row)` (the first 16 bytes of the record) is issued one
+// candidate ahead of `eval(row, record)`.
+template <class Fetch, class Eval>
+__device__ __forceinline__ void mfma_flush_prefetch(uint32_t nz, const uint32_t* bm, Fetch&& fetch, Eval&& eval) {
+    CandIter it = { nz, 0u, 0u };
+    uint32_t row = 0, rown = 0;
+    bool have = cand_next(it, bm, row);
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f), recn = rec;
+    if (have) rec = fetch(row);
+    while (have) {
+        const bool haven = cand_next(it, bm, rown);
+        if (haven) recn = fetch(rown);
+        eval(row, rec);
+        row = rown; rec = recn; have = haven;
     }
 }
 
@@ -804,8 +808,8 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     float4* s_mat = s_sph + (size_t)n_blocks * 32;                               // materials, kinds, 1/r: read at every hit
     float* s_invr = reinterpret_cast<float*>(s_mat + (size_t)n_blocks * 32);
     uint32_t* s_kind = reinterpret_cast<uint32_t*>(s_invr + (size_t)n_blocks * 32);
-    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_kind + (size_t)n_blocks * 32);   // [2][kMQ][kMB]
-    const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5;
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_kind + (size_t)n_blocks * 32); // [16][kMB] candidate words
+    const uint32_t tid = threadIdx.x, lane = lane_id();
     for (uint32_t k = tid; k < n_blocks * 256; k += kMB) s_frag[k] = frags[k];
     for (uint32_t k = tid; k < n_blocks * 32; k += kMB) {
         const bool in = k < A.n_sph;
@@ -832,12 +836,11 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
         iters++;
         const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
         RayOperands R;
-        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, half, R);
+        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, R);
 
         // nearest hit: exact evaluation of queued candidates (ties: lower sphere index, as the sequential loop)
         float tbest = __builtin_inff();
         uint32_t ibest = 0, kind = 0;
-        uint32_t nq[2] = { 0, 0 };
         auto eval = [&](uint32_t j) {
             const float4 s = s_sph[j];
             const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
@@ -850,9 +853,8 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             if (!(t > A.t_min)) t = h + sq;
             if (t > A.t_min && (t < tbest || (t == tbest && j < ibest))) { tbest = t; ibest = j; kind = 2; }
         };
-        auto flush = [&]() { mfma_flush(s_q, tid, half, nq, eval); };
-        mfma_scan_tile(s_frag, n_blocks, R, s_q, tid, lane, half, nq, flush);
-        flush();
+        const uint32_t nz = mfma_scan_tile(s_frag, n_blocks, R, s_bm + tid, lane);
+        mfma_flush(nz, s_bm + tid, eval);
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
     }
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
@@ -865,8 +867,8 @@ template <bool HAS_TRI, bool HAS_SPH>
 __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;                                                   // [16][4][64]
-    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_frag + 16 * 256);              // [2][kMQ][kMB]
-    const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5;
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);           // [16][kMB] candidate words
+    const uint32_t tid = threadIdx.x, lane = lane_id();
 
     Path P;
     P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
@@ -883,10 +885,9 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
         casts += (unsigned long long)__popcll(live);
         const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
         RayOperands R;
-        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, half, R);
+        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, R);
         float tbest = __builtin_inff();
         uint32_t ibest = 0, kind = 0;
-        uint32_t nq[2] = { 0, 0 };
 
         auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& fetch_row, auto&& eval_row) {
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
@@ -895,12 +896,9 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
                 __syncthreads();                                                // every wave is done with the previous tile
                 for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = frags[(size_t)b0 * 256 + k];
                 __syncthreads();
-                auto flush = [&]() {
-                    mfma_flush_prefetch(s_q, tid, half, nq, [&](uint32_t row) { return fetch_row(b0 * 32u + row); },
-                                        [&](uint32_t row, const float4 rec) { eval_row(b0 * 32u + row, rec); });
-                };
-                mfma_scan_tile(s_frag, nb, R, s_q, tid, lane, half, nq, flush);
-                flush();
+                const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
+                mfma_flush_prefetch(nz, s_bm + tid, [&](uint32_t row) { return fetch_row(b0 * 32u + row); },
+                                    [&](uint32_t row, const float4 rec) { eval_row(b0 * 32u + row, rec); });
                 mfmas += nb * 8ull;
             }
         };
@@ -936,8 +934,8 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
                                                     uint32_t width, uint32_t height, uint32_t* __restrict__ out) {
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;
-    uint8_t* s_q = reinterpret_cast<uint8_t*>(s_frag + 16 * 256);
-    const uint32_t tid = threadIdx.x, lane = lane_id(), half = lane >> 5;
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);
+    const uint32_t tid = threadIdx.x, lane = lane_id();
     const uint32_t pixel = blockIdx.x * kMB + tid;
     const bool valid = pixel < width * height;
     const uint32_t x = valid ? pixel % width : 0u, y = valid ? pixel / width : 0u;
@@ -949,11 +947,10 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
     const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
     const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));     // unit direction for the filter only
     RayOperands R;
-    build_ray_operands(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid, half, R);
+    build_ray_operands(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid, R);
 
     uint32_t min_i = 0;
     float min_t = __builtin_inff();
-    uint32_t nq[2] = { 0, 0 };
     const uint32_t total_blocks = (n_faces + 31u) / 32u;
     for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
         const uint32_t nb = min(16u, total_blocks - b0);
@@ -982,11 +979,8 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
             if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
             if (t < min_t || j < min_i) { min_i = j; min_t = t; }   // "t >= min_t rejects" of :71 == the lowest index wins ties
         };
-        auto flush = [&]() {
-            mfma_flush_prefetch(s_q, tid, half, nq, [&](uint32_t row) { return tri[(size_t)min(b0 * 32u + row, n_faces - 1u) * 4]; }, eval);
-        };
-        mfma_scan_tile(s_frag, nb, R, s_q, tid, lane, half, nq, flush);
-        flush();
+        const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
+        mfma_flush_prefetch(nz, s_bm + tid, [&](uint32_t row) { return tri[(size_t)min(b0 * 32u + row, n_faces - 1u) * 4]; }, eval);
     }
     if (!valid) return;
     float r, g, b;
@@ -1111,12 +1105,12 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
         bound_frag_row(cx, cy, cz, kj, fr);
         for (int q = 0; q < 4; q++)
             for (int hh = 0; hh < 2; hh++)
-                frag[((size_t)(i / 32) * 4 + q) * 64 + hh * 32 + (i % 32)] = u32x4{ fr[q][hh][0], fr[q][hh][1], fr[q][hh][2], fr[q][hh][3] };
+                frag[((size_t)(i / 32) * 4 + q) * 64 + hh * 32 + frag_row_of(i % 32)] = u32x4{ fr[q][hh][0], fr[q][hh][1], fr[q][hh][2], fr[q][hh][3] };
     };
     if (i >= n_pad && i >= n_frag_rows) return;
-    if (i >= n_faces) { if (i < n_pad) bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, 1e30f); return; }
+    if (i >= n_faces) { if (i < n_pad) bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
     const rt3_gface f = faces[i];
-    if (f.v1 >= n_verts || f.v2 >= n_verts || f.v3 >= n_verts) { atomicOr(error_flag, 1u); bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, 1e30f); return; }
+    if (f.v1 >= n_verts || f.v2 >= n_verts || f.v3 >= n_verts) { atomicOr(error_flag, 1u); bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
     const float4 p1 = verts[f.v1], p2 = verts[f.v2], p3 = verts[f.v3];
     tri[4 * (size_t)i] = make_float4(f.normal[0], f.normal[1], f.normal[2], dot3(f.normal[0], f.normal[1], f.normal[2], p1.x, p1.y, p1.z));
     tri[4 * (size_t)i + 1] = make_float4(p1.x, p1.y, p1.z, 0.0f);
@@ -1140,7 +1134,7 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
     {
         const float fx = (float)cx, fy = (float)cy, fz = (float)cz;
         const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
-        write_frag(fx, fy, fz, r2f < __builtin_inff() ? filter_kj(c2, (double)r2f) : -1e30f);    // r^2 = inf: always a candidate
+        write_frag(fx, fy, fz, r2f < __builtin_inff() ? filter_kj(c2, (double)r2f) : kAlwaysCandidate);   // r^2 = inf: the exact test decides
     }
     if (mats) {
         const rt3_material m = mats[i];
@@ -1296,7 +1290,8 @@ float4 pack_material(const rt3_material& m) {
 }
 
 // Sphere-side operand fragments of the matrix filter: [row block of 32 spheres][4 MFMA operands][64 lanes] x 8 bf16.
-// Lane l holds, for sphere (l & 31) of the block, K elements 8 (l >> 5) .. +7 of the operand; padding rows can never be candidates.
+// Lane l holds, for operand row (l & 31) — sphere b of the block sits in row frag_row_of(b) — K elements 8 (l >> 5) .. +7;
+// padding rows can never be candidates.
 std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n) {
     const uint32_t blocks = (n + 31u) / 32u;
     std::vector<uint32_t> out((size_t)blocks * 4 * 64 * 4, 0u);
@@ -1306,10 +1301,10 @@ std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n)
             const float* s = center_radius + 4 * (size_t)j;
             const double c2 = (double)s[0] * s[0] + (double)s[1] * s[1] + (double)s[2] * s[2], r2 = (double)s[3] * s[3];
             bound_frag_row(s[0], s[1], s[2], filter_kj(c2, r2), fr);
-        } else bound_frag_row(0.0f, 0.0f, 0.0f, 1e30f, fr);
+        } else bound_frag_row(0.0f, 0.0f, 0.0f, kNeverCandidate, fr);
         for (int q = 0; q < 4; q++)
             for (int hh = 0; hh < 2; hh++)
-                std::memcpy(&out[((((size_t)(j / 32) * 4 + q) * 64) + hh * 32 + (j % 32)) * 4], fr[q][hh], 16);
+                std::memcpy(&out[((((size_t)(j / 32) * 4 + q) * 64) + hh * 32 + frag_row_of(j % 32)) * 4], fr[q][hh], 16);
     }
     return out;
 }
@@ -1540,7 +1535,7 @@ int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint3
     // any other camera takes the plain brute-force kernel, which reproduces the reference for every input.
     const bool at_origin = cam->origin[0] == 0.0f && cam->origin[1] == 0.0f && cam->origin[2] == 0.0f;
     if (at_origin && !ctx->force_plain_mode_r && !getenv("RT3_NO_MFMA") && ctx->n_faces > 0) {
-        const size_t lds = (size_t)16 * 4096 + (size_t)2 * kMQ * kMB;
+        const size_t lds = (size_t)16 * 4096 + (size_t)kBitmapBytes;
         RT3_HIP(hipFuncSetAttribute((const void*)k_mode_r_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_mode_r_mfma, dim3((npix + kMB - 1) / kMB), dim3(kMB), lds, stream,
                            ctx->d_tri, (const u32x4*)ctx->d_tri_frag, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
@@ -1643,8 +1638,8 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     const bool use_mfma = !getenv("RT3_NO_MFMA");
     const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax;
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
-    const size_t mfma_lds = mfma_single ? (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)2 * kMQ * kMB
-                                        : (size_t)16 * 4096 + (size_t)2 * kMQ * kMB;
+    const size_t mfma_lds = mfma_single ? (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)kBitmapBytes
+                                        : (size_t)16 * 4096 + (size_t)kBitmapBytes;
     using TiledKernel = void (*)(const TraceArgs, const u32x4*, const u32x4*);
     const TiledKernel tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true> : k_trace_mfma_tiled<true, false>) : k_trace_mfma_tiled<false, true>;
     int per_cu = 0;
