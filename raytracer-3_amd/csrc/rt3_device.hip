@@ -622,14 +622,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// K-slot table, shared by the host (sphere fragments) and the device (ray fragments).  Slot s of the 64: s < 54 is term s % 9 in
-// cross product s / 9; 54..56 are the parts of K_j against the ray's constant 1; 57..59 the parts of E_i against the sphere's
-// constant 1; 60..63 are empty.  part: 0 = H, 1 = M, 2 = L, 3 = zero.
-__host__ __device__ constexpr int combo_ray_part(int c) { return c == 0 ? 0 : c == 1 ? 0 : c == 2 ? 1 : c == 3 ? 0 : c == 4 ? 2 : 1; }
-__host__ __device__ constexpr int combo_sph_part(int c) { return c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 0 : c == 3 ? 2 : c == 4 ? 0 : 1; }
-__host__ __device__ constexpr int slot_term(int s) { return s < 54 ? s % 9 : s < 57 ? 9 : s < 60 ? 10 : 11; }
-__host__ __device__ constexpr int slot_ray_part(int s) { return s < 54 ? combo_ray_part(s / 9) : s < 57 ? 0 : s < 60 ? s - 57 : 3; }
-__host__ __device__ constexpr int slot_sph_part(int s) { return s < 54 ? combo_sph_part(s / 9) : s < 57 ? s - 54 : s < 60 ? 0 : 3; }
+// K-slot layout.  Operand q (0..3) of the chain holds 16 K-elements, lane half hh supplies elements 8 hh .. 8 hh + 7 as four
+// dwords i = 0..3 of two bf16 each.  With x_t / y_t the ray / sphere factor of term t (t = 0..8), E and K the two constants:
+//     (q = 0,1,2; hh = 0)  ray (H x_2i, H x_2i+1)                      sphere (P y_2i, P y_2i+1),  P = H, M, L for q = 0, 1, 2
+//     (q = 0,1;   hh = 1)  ray (M x_2i, M x_2i+1)                      sphere (P y_2i, P y_2i+1),  P = H, M
+//     (q = 2;     hh = 1)  ray (L x_2i, L x_2i+1)                      sphere (H y_2i, H y_2i+1)
+//     (q = 3;     hh = 0)  ray (H x_8, 1) x3, (M x_8, H E)             sphere (H y_8, H K), (M y_8, M K), (L y_8, L K), (H y_8, 1)
+//     (q = 3;     hh = 1)  ray (M x_8, M E), (L x_8, L E), 0, 0        sphere (M y_8, 1), (H y_8, 1), 0, 0
+// so a lane needs only three distinct ray-side register quads per column set (operands 0 and 1 share one).
 // row of the A operand that holds sphere b (0..31) of a row block
 __host__ __device__ constexpr uint32_t frag_row_of(uint32_t b) { return ((15u - (b & 15u)) & 3u) + 8u * ((15u - (b & 15u)) >> 2) + 4u * (b >> 4); }
 
@@ -649,63 +649,83 @@ __host__ __device__ inline void split3(float x, uint32_t* parts /*[3]*/) {
 // Sphere-side (A operand) fragment of one bounding sphere: out[q][hh][dword] = K elements 8 hh .. 8 hh + 7 of MFMA operand q.
 // kj = filter_kj(|C|^2, r^2); a padding row uses C = 0, kj = -1e30 (never a candidate), an unbounded one kj = +1e30 (always).
 __host__ __device__ inline void bound_frag_row(float cx, float cy, float cz, float kj, uint32_t out[4][2][4]) {
-    uint32_t f[11][3];                                              // [term][part]
-    const double x = cx, y = cy, z = cz;
-    split3((float)(x * x), f[0]); split3((float)(y * y), f[1]); split3((float)(z * z), f[2]);
-    split3((float)(x * y), f[3]); split3((float)(x * z), f[4]); split3((float)(y * z), f[5]);
-    split3(cx, f[6]); split3(cy, f[7]); split3(cz, f[8]);
-    split3(kj, f[9]);
-    f[10][0] = 0x3F80u; f[10][1] = 0u; f[10][2] = 0u;               // the constant 1
-    for (int q = 0; q < 4; q++)
-        for (int hh = 0; hh < 2; hh++)
-            for (int d = 0; d < 4; d++) {
-                uint32_t w = 0;
-                for (int e = 0; e < 2; e++) {
-                    const int sl = 16 * q + 8 * hh + 2 * d + e;
-                    const int part = slot_sph_part(sl), term = slot_term(sl);
-                    w |= (part == 3 || term == 11 ? 0u : f[term][part]) << (16 * e);
-                }
-                out[q][hh][d] = w;
-            }
+    uint32_t y[9][3], k[3];                                         // [term][part]
+    const double x = cx, yy = cy, z = cz;
+    split3((float)(x * x), y[0]); split3((float)(yy * yy), y[1]); split3((float)(z * z), y[2]);
+    split3((float)(x * yy), y[3]); split3((float)(x * z), y[4]); split3((float)(yy * z), y[5]);
+    split3(cx, y[6]); split3(cy, y[7]); split3(cz, y[8]);
+    split3(kj, k);
+    const uint32_t one = 0x3F80u;
+    auto pk = [](uint32_t lo, uint32_t hi) { return lo | (hi << 16); };
+    for (int i = 0; i < 4; i++) {
+        for (int q = 0; q < 3; q++) out[q][0][i] = pk(y[2 * i][q], y[2 * i + 1][q]);
+        for (int q = 0; q < 2; q++) out[q][1][i] = pk(y[2 * i][q], y[2 * i + 1][q]);
+        out[2][1][i] = pk(y[2 * i][0], y[2 * i + 1][0]);
+    }
+    for (int i = 0; i < 3; i++) out[3][0][i] = pk(y[8][i], k[i]);
+    out[3][0][3] = pk(y[8][0], one);
+    out[3][1][0] = pk(y[8][1], one);
+    out[3][1][1] = pk(y[8][0], one);
+    out[3][1][2] = 0u; out[3][1][3] = 0u;
 }
 __host__ __device__ inline float filter_kj(double c2, double r2) { return (float)((r2 - c2) + (double)kFilterEps * (c2 + r2)); }
 constexpr float kNeverCandidate = -1e30f, kAlwaysCandidate = 1e30f;
 
-// Ray-side (B operand) fragments of the 64 rays of a wave, for both column sets (rays 0..31 / 32..63).
-struct RayOperands { u32x4 b[2][4]; };
+// Ray-side (B operand) fragments of the 64 rays of a wave: [column set (rays 0..31 / 32..63)][operands 0 and 1, operand 2, operand 3].
+struct RayOperands { u32x4 b[2][3]; };
+// v_cvt_pk_bf16_f32 (round to nearest even, two floats -> one dword).  HARDWARE NOTE (measured on MI355X, ROCm 7.2): a VALU
+// instruction that consumes the result straight after the conversion can read a stale register — about one ray in 10^6 lost a
+// candidate, differently in every run, until wait states were added; hipcc's hazard recognizer inserts none for this opcode
+// (it does for v_permlane32_swap).  The conversion is therefore issued through inline asm with its own `s_nop 3`, which also
+// covers the two wait states a following v_permlane32_swap needs.  tests/test_gpu_repeatability.py guards the property.
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 3" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// v_permlane32_swap(x, y): x's upper half-wave <-> y's lower half-wave; set0 = new x, set1 = new y
+__device__ __forceinline__ void swap32(uint32_t x, uint32_t y, uint32_t& set0, uint32_t& set1) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    set0 = r[0]; set1 = r[1];
+}
+__device__ __forceinline__ float pk_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float pk_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
 __device__ __forceinline__ void build_ray_operands(float ox, float oy, float oz, float dx, float dy, float dz, bool alive, RayOperands& R) {
-    uint32_t f[11][3];                                              // [term][part]
     const float od = dotf(ox, oy, oz, dx, dy, dz), oo = dotf(ox, oy, oz, ox, oy, oz);
-    split3(dx * dx, f[0]); split3(dy * dy, f[1]); split3(dz * dz, f[2]);
-    split3(2.0f * dx * dy, f[3]); split3(2.0f * dx * dz, f[4]); split3(2.0f * dy * dz, f[5]);
-    split3(2.0f * (ox - od * dx), f[6]); split3(2.0f * (oy - od * dy), f[7]); split3(2.0f * (oz - od * dz), f[8]);
-    f[9][0] = 0x3F80u; f[9][1] = 0u; f[9][2] = 0u;                  // the constant 1
-    split3(alive ? od * od - oo * (1.0f - kFilterEps) : -3e30f, f[10]);   // a dead lane's column can never produce a candidate
-    // own[d]: dword d (K elements 2d, 2d+1 of the operand's 16).  The B fragment of column set S: lane (w, col) supplies elements
-    // 8 w .. 8 w + 7 of ray 32 S + col — lanes 0-31 keep their elements 0-7 for set 0 and need their partner's 0-7 for set 1; lanes
-    // 32-63 the mirror image: exactly one v_permlane32_swap per dword pair (x's upper half <-> y's lower half).
+    float x[9] = { dx * dx, dy * dy, dz * dz, 2.0f * dx * dy, 2.0f * dx * dz, 2.0f * dy * dz,
+                   2.0f * (ox - od * dx), 2.0f * (oy - od * dy), 2.0f * (oz - od * dz) };
+    float e = alive ? od * od - oo * (1.0f - kFilterEps) : -3e30f;      // a dead lane's column can never produce a candidate
+    // three-way bf16 split of the ten factors, two at a time: part = cvt_pk(residuals), residual -= part
+    uint32_t ph[4], pm[4], pl[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint32_t own[8];
+    for (int i = 0; i < 4; i++) { ph[i] = pk_bf16(x[2 * i], x[2 * i + 1]); x[2 * i] -= pk_lo(ph[i]); x[2 * i + 1] -= pk_hi(ph[i]); }
+    const uint32_t h8 = pk_bf16(x[8], 1.0f);
+    x[8] -= pk_lo(h8);
 #pragma unroll
-        for (int d = 0; d < 8; d++) {
-            uint32_t e[2];
+    for (int i = 0; i < 4; i++) { pm[i] = pk_bf16(x[2 * i], x[2 * i + 1]); x[2 * i] -= pk_lo(pm[i]); x[2 * i + 1] -= pk_hi(pm[i]); }
+    const uint32_t m8a = pk_bf16(x[8], e);
+    e -= pk_hi(m8a);
+    const uint32_t m8b = pk_bf16(x[8], e);
+    e -= pk_hi(m8b);
+    x[8] -= pk_lo(m8a);
 #pragma unroll
-            for (int z = 0; z < 2; z++) {
-                const int sl = 16 * q + 2 * d + z;
-                const int part = slot_ray_part(sl), term = slot_term(sl);
-                e[z] = (part == 3 || term == 11) ? 0u : f[term][part];
-            }
-            own[d] = e[0] | (e[1] << 16);
-        }
-        uint32_t s0[4], s1[4];
+    for (int i = 0; i < 4; i++) pl[i] = pk_bf16(x[2 * i], x[2 * i + 1]);
+    const uint32_t l8 = pk_bf16(x[8], e);
+    // Lane (w, col) supplies elements 8 w .. 8 w + 7 of ray 32 S + col for column set S: lanes 0-31 keep their hh = 0 dwords for
+    // set 0 and need their partner's for set 1, lanes 32-63 the mirror image with hh = 1 — v_permlane32_swap(a, b) exchanges a's
+    // upper half with b's lower half, so swapping an (hh = 0 dword, hh = 1 dword) pair leaves the set-0 dword in a, set 1 in b.
+    uint32_t s0[3][4], s1[3][4];
+    const uint32_t lo3[4] = { h8, h8, h8, m8a }, hi3[4] = { m8b, l8, 0u, 0u };
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const auto sw = __builtin_amdgcn_permlane32_swap(own[i], own[4 + i], false, false);
-            s0[i] = sw[0]; s1[i] = sw[1];
-        }
-        R.b[0][q] = u32x4{ s0[0], s0[1], s0[2], s0[3] };
-        R.b[1][q] = u32x4{ s1[0], s1[1], s1[2], s1[3] };
+    for (int i = 0; i < 4; i++) {
+        swap32(ph[i], pm[i], s0[0][i], s1[0][i]);
+        swap32(ph[i], pl[i], s0[1][i], s1[1][i]);
+        swap32(lo3[i], hi3[i], s0[2][i], s1[2][i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        R.b[0][k] = u32x4{ s0[k][0], s0[k][1], s0[k][2], s0[k][3] };
+        R.b[1][k] = u32x4{ s1[k][0], s1[k][1], s1[k][2], s1[k][3] };
     }
 }
 
@@ -721,12 +741,12 @@ __device__ __forceinline__ uint32_t mfma_scan_tile(const u32x4* s_frag, uint32_t
         const f32x16 zero = { 0 };
         f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[0][0]), zero, 0, 0, 0);
         f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[1][0]), zero, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[0][1]), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[1][1]), d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[0][2]), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[1][2]), d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[0][3]), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[1][3]), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[0][0]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[1][0]), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[0][1]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[1][1]), d1, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[0][2]), d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[1][2]), d1, 0, 0, 0);
         uint32_t n0 = 0xFFFFFFFFu, n1 = 0xFFFFFFFFu;               // sign bits: register g -> bit 15 - g
 #pragma unroll
         for (int g = 0; g < 16; g++) n0 = __builtin_amdgcn_alignbit(n0, __float_as_uint(d0[g]), 31);
