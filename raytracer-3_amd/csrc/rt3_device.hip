@@ -416,6 +416,53 @@ __device__ __forceinline__ void refill_lanes(const TraceArgs& A, uint32_t lane, 
     }
 }
 
+// Refill through a wave-wide stock of primary rays: start_path() runs for all 64 lanes at once (lane k of the stock holds sample
+// chunk_next + k) and lanes whose path ended pop entries off the top with ds_bpermute — the ~250 instructions of start_path are
+// then paid per 64 new paths instead of per loop iteration (in which about a third of the lanes end).
+struct RayStock { float ox, oy, oz, dx, dy, dz; uint32_t slot, base; uint32_t n; };   // n: wave-uniform count, entries in lanes [0, n)
+__device__ __forceinline__ void stock_pop(const RayStock& Q, uint32_t src, bool take, Path& P, bool& alive) {
+    const int s = (int)src;
+    const float ox = __shfl(Q.ox, s), oy = __shfl(Q.oy, s), oz = __shfl(Q.oz, s), dx = __shfl(Q.dx, s), dy = __shfl(Q.dy, s), dz = __shfl(Q.dz, s);
+    const uint32_t slot = (uint32_t)__shfl((int)Q.slot, s), base = (uint32_t)__shfl((int)Q.base, s);
+    if (take) {
+        P.ox = ox; P.oy = oy; P.oz = oz; P.dx = dx; P.dy = dy; P.dz = dz; P.slot = slot; P.base = base;
+        P.tr = P.tg = P.tb = 1.0f; P.lr = P.lg = P.lb = 0.0f; P.depth = 0;
+        alive = true;
+    }
+}
+__device__ __forceinline__ void refill_from_stock(const TraceArgs& A, uint32_t lane, bool& alive, Path& P, RayStock& Q, uint32_t& chunk_next,
+                                                  uint32_t& chunk_end, bool& exhausted) {
+    const unsigned long long need = __ballot(!alive);
+    if (need == 0ull) return;
+    const uint32_t n_need = (uint32_t)__popcll(need), rank = prefix_count(need);
+    uint32_t served = 0;
+    for (;;) {
+        const uint32_t k = min(Q.n, n_need - served);
+        if (k != 0) {
+            const bool take = !alive && rank >= served && rank < served + k;
+            stock_pop(Q, Q.n - 1u - (rank - served), take, P, alive);       // (the index only matters where take is set)
+            Q.n -= k;
+            served += k;
+        }
+        if (served == n_need || exhausted) return;
+        // the stock is empty: restock from the wave's chunk (one atomic per kWorkChunk samples)
+        if (chunk_next == chunk_end) {
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(A.work_counter, kWorkChunk);
+            b = __builtin_amdgcn_readfirstlane(b);
+            if (b >= A.total) { exhausted = true; return; }
+            chunk_next = b;
+            chunk_end = min(b + kWorkChunk, A.total);
+        }
+        const uint32_t n_new = min(64u, chunk_end - chunk_next);
+        Path T;
+        start_path(A, min(chunk_next + lane, chunk_end - 1u), T);
+        Q.ox = T.ox; Q.oy = T.oy; Q.oz = T.oz; Q.dx = T.dx; Q.dy = T.dy; Q.dz = T.dz; Q.slot = T.slot; Q.base = T.base;
+        Q.n = n_new;
+        chunk_next += n_new;
+    }
+}
+
 // Shade / scatter one ray cast of every live lane (book materials).  kind: 0 miss, 1 face, 2 sphere.
 // The four per-sphere arrays read at a hit are parameters: global memory in k_trace, LDS copies in k_trace_mfma.
 template <bool HAS_TRI, bool HAS_SPH>
@@ -846,10 +893,15 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     bool alive = false;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
+    RayStock Q;
+    Q.ox = Q.oy = Q.oz = 0.0f; Q.dx = Q.dy = 0.0f; Q.dz = 1.0f; Q.slot = 0; Q.base = 0; Q.n = 0;
     unsigned long long casts = 0, iters = 0;
+#ifdef RT3_PROFILE
+    unsigned long long prof_flush_iters = 0, prof_cands = 0, prof_refills = 0;
+#endif
 
     for (;;) {
-        refill_lanes(A, lane, alive, P, chunk_next, chunk_end, exhausted);
+        refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
         const unsigned long long live = __ballot(alive);
         if (live == 0ull) break;
         casts += (unsigned long long)__popcll(live);
@@ -874,10 +926,25 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             if (t > A.t_min && (t < tbest || (t == tbest && j < ibest))) { tbest = t; ibest = j; kind = 2; }
         };
         const uint32_t nz = mfma_scan_tile(s_frag, n_blocks, R, s_bm + tid, lane);
+#ifdef RT3_PROFILE
+        {
+            uint32_t mine = 0;
+            CandIter it = { nz, 0u, 0u };
+            uint32_t row;
+            while (cand_next(it, s_bm + tid, row)) mine++;
+            uint32_t mx = mine, sm = mine;
+            for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sm += (uint32_t)__shfl_xor((int)sm, o); }
+            prof_flush_iters += mx; prof_cands += sm;
+            prof_refills += (uint32_t)__popcll(__ballot(P.depth == 0 && alive));
+        }
+#endif
         mfma_flush(nz, s_bm + tid, eval);
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
     }
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
+#ifdef RT3_PROFILE
+    if (lane == 0) { atomicAdd(A.cast_counter + 2, prof_flush_iters); atomicAdd(A.cast_counter + 3, prof_cands); atomicAdd(A.cast_counter + 4, iters); atomicAdd(A.cast_counter + 5, prof_refills); }
+#endif
 }
 
 // Any scene: faces (through their bounding spheres) and spheres, streamed through LDS in tiles of 512 rows.  The 16 waves of the
@@ -1606,7 +1673,7 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     ctx->last_was_path = true;
     ctx->rendered = true;
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
-    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 16, stream));
+    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 64, stream));
     if (npix == 0) { RT3_HIP(hipEventRecord(ctx->ev_end, stream)); return 0; }
 
     // batch size: per-sample storage of 16 B per (pixel, sample), capped
@@ -1733,8 +1800,13 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
     out->n_spheres = ctx->n_sph;
     out->n_faces = ctx->n_faces;
     if (ctx->last_was_path) {
-        unsigned long long counters[2] = { 0, 0 };
-        RT3_HIP(hipMemcpy(counters, ctx->d_casts, 16, hipMemcpyDeviceToHost));
+        unsigned long long counters[8] = { 0 };
+        RT3_HIP(hipMemcpy(counters, ctx->d_casts, 64, hipMemcpyDeviceToHost));
+#ifdef RT3_PROFILE
+        fprintf(stderr, "[rt3 profile] wave iterations %llu, flush iterations/wave-iter %.2f, candidates/ray %.2f, live lanes/wave-iter %.1f, "
+                        "fresh paths/wave-iter %.1f\n", counters[4], (double)counters[2] / (double)counters[4],
+                (double)counters[3] / (double)counters[0], (double)counters[0] / (double)counters[4], (double)counters[5] / (double)counters[4]);
+#endif
         out->ray_casts = counters[0];
         out->prim_tests = counters[0] * ((uint64_t)ctx->n_sph + ctx->n_faces);
         out->mfma_instructions = counters[1];
