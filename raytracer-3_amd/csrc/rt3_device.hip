@@ -963,10 +963,12 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
     bool alive = false;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
+    RayStock Q;
+    Q.ox = Q.oy = Q.oz = 0.0f; Q.dx = Q.dy = 0.0f; Q.dz = 1.0f; Q.slot = 0; Q.base = 0; Q.n = 0;
     unsigned long long casts = 0, mfmas = 0;
 
     for (;;) {
-        refill_lanes(A, lane, alive, P, chunk_next, chunk_end, exhausted);
+        refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
         const unsigned long long live = __ballot(alive);
         if (!__syncthreads_or(live != 0ull ? 1 : 0)) break;                      // the workgroup ends together
         casts += (unsigned long long)__popcll(live);
