@@ -780,41 +780,50 @@ __device__ __forceinline__ void build_ray_operands(float ox, float oy, float oz,
 // per row block 8 MFMAs, 32 v_alignbit and one exchange.  Candidate word `blk` of this lane's ray goes to bm[blk * kMB] (bit b
 // CLEAR <-> sphere 32 blk + b is a candidate); the return value has bit blk set when that word holds any candidate.
 __device__ __forceinline__ uint32_t mfma_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands& R, uint32_t* bm, uint32_t lane) {
-    uint32_t nz = 0;
-    for (uint32_t blk = 0; blk < n_blocks; blk++) {
-        const u32x4* fr = s_frag + (size_t)blk * 256 + lane;
-        const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
-        const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
-        const f32x16 zero = { 0 };
-        f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[0][0]), zero, 0, 0, 0);
-        f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[1][0]), zero, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[0][0]), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[1][0]), d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[0][1]), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[1][1]), d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[0][2]), d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[1][2]), d1, 0, 0, 0);
-        uint32_t n0 = 0xFFFFFFFFu, n1 = 0xFFFFFFFFu;               // sign bits: register g -> bit 15 - g
+    uint32_t nz = 0;                                                // block blk -> bit n_blocks - 1 - blk
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {                 // four row blocks per trip: their LDS offsets are immediates
+        const u32x4* fr0 = s_frag + (size_t)b0 * 256 + lane;
+        uint32_t* bm0 = bm + b0 * kMB;
 #pragma unroll
-        for (int g = 0; g < 16; g++) n0 = __builtin_amdgcn_alignbit(n0, __float_as_uint(d0[g]), 31);
+        for (uint32_t u = 0; u < 4; u++) {
+            if (b0 + u >= n_blocks) break;
+            const u32x4* fr = fr0 + u * 256;
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
+            const f32x16 zero = { 0 };
+            f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[0][0]), zero, 0, 0, 0);
+            f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[1][0]), zero, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[0][0]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[1][0]), d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[0][1]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[1][1]), d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[0][2]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[1][2]), d1, 0, 0, 0);
+            uint32_t n0 = 0xFFFFFFFFu, n1 = 0xFFFFFFFFu;           // sign bits: register g -> bit 15 - g
 #pragma unroll
-        for (int g = 0; g < 16; g++) n1 = __builtin_amdgcn_alignbit(n1, __float_as_uint(d1[g]), 31);
-        // lower lanes: own set-0 signs (rows of half 0) + the partner's set-0 signs (rows of half 1); upper lanes: set 1
-        const auto sw = __builtin_amdgcn_permlane32_swap(n0, n1, false, false);
-        const uint32_t w = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);
-        bm[blk * kMB] = w;
-        nz |= w != 0xFFFFFFFFu ? 1u << blk : 0u;
+            for (int g = 0; g < 16; g++) n0 = __builtin_amdgcn_alignbit(n0, __float_as_uint(d0[g]), 31);
+#pragma unroll
+            for (int g = 0; g < 16; g++) n1 = __builtin_amdgcn_alignbit(n1, __float_as_uint(d1[g]), 31);
+            // lower lanes: own set-0 signs (rows of half 0) + the partner's set-0 signs (rows of half 1); upper lanes: set 1
+            const auto sw = __builtin_amdgcn_permlane32_swap(n0, n1, false, false);
+            const uint32_t w = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);
+            bm0[u * kMB] = w;
+            // nz = 2 nz + (w != ~0): compare into VCC, add with carry (the two wait states between a VALU write of VCC and a
+            // VALU read of it are what hipcc itself inserts on gfx950)
+            asm("v_cmp_ne_u32_e32 vcc, -1, %1\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(nz) : "v"(w) : "vcc");
+        }
     }
     return nz;
 }
 
 // Exact tests of the parked candidates of this lane's ray, in ascending sphere order.
-struct CandIter { uint32_t nz, bits, blk; };
+struct CandIter { uint32_t nz, bits, blk, nb; };
 __device__ __forceinline__ bool cand_next(CandIter& it, const uint32_t* bm, uint32_t& row) {
     if (it.bits == 0u) {
         if (it.nz == 0u) return false;
-        it.blk = (uint32_t)__builtin_ctz(it.nz);
-        it.nz &= it.nz - 1u;
+        const uint32_t hb = 31u - (uint32_t)__builtin_clz(it.nz);
+        it.blk = it.nb - 1u - hb;
+        it.nz ^= 1u << hb;
         it.bits = ~bm[it.blk * kMB];                                // non-zero: the scan set this word's nz bit
     }
     row = it.blk * 32u + (uint32_t)__builtin_ctz(it.bits);
@@ -822,16 +831,16 @@ __device__ __forceinline__ bool cand_next(CandIter& it, const uint32_t* bm, uint
     return true;
 }
 template <class Eval>
-__device__ __forceinline__ void mfma_flush(uint32_t nz, const uint32_t* bm, Eval&& eval) {
-    CandIter it = { nz, 0u, 0u };
+__device__ __forceinline__ void mfma_flush(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, Eval&& eval) {
+    CandIter it = { nz, 0u, 0u, n_blocks };
     uint32_t row;
     while (cand_next(it, bm, row)) eval(row);
 }
 // Same, for exact tests that gather from global memory: `fetch(row)` (the first 16 bytes of the record) is issued one
 // candidate ahead of `eval(row, record)`.
 template <class Fetch, class Eval>
-__device__ __forceinline__ void mfma_flush_prefetch(uint32_t nz, const uint32_t* bm, Fetch&& fetch, Eval&& eval) {
-    CandIter it = { nz, 0u, 0u };
+__device__ __forceinline__ void mfma_flush_prefetch(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, Fetch&& fetch, Eval&& eval) {
+    CandIter it = { nz, 0u, 0u, n_blocks };
     uint32_t row = 0, rown = 0;
     bool have = cand_next(it, bm, row);
     float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f), recn = rec;
@@ -929,7 +938,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
 #ifdef RT3_PROFILE
         {
             uint32_t mine = 0;
-            CandIter it = { nz, 0u, 0u };
+            CandIter it = { nz, 0u, 0u, n_blocks };
             uint32_t row;
             while (cand_next(it, s_bm + tid, row)) mine++;
             uint32_t mx = mine, sm = mine;
@@ -938,7 +947,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             prof_refills += (uint32_t)__popcll(__ballot(P.depth == 0 && alive));
         }
 #endif
-        mfma_flush(nz, s_bm + tid, eval);
+        mfma_flush(nz, n_blocks, s_bm + tid, eval);
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
     }
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
@@ -986,7 +995,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
                 for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = frags[(size_t)b0 * 256 + k];
                 __syncthreads();
                 const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-                mfma_flush_prefetch(nz, s_bm + tid, [&](uint32_t row) { return fetch_row(b0 * 32u + row); },
+                mfma_flush_prefetch(nz, nb, s_bm + tid, [&](uint32_t row) { return fetch_row(b0 * 32u + row); },
                                     [&](uint32_t row, const float4 rec) { eval_row(b0 * 32u + row, rec); });
                 mfmas += nb * 8ull;
             }
@@ -1069,7 +1078,7 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
             if (t < min_t || j < min_i) { min_i = j; min_t = t; }   // "t >= min_t rejects" of :71 == the lowest index wins ties
         };
         const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-        mfma_flush_prefetch(nz, s_bm + tid, [&](uint32_t row) { return tri[(size_t)min(b0 * 32u + row, n_faces - 1u) * 4]; }, eval);
+        mfma_flush_prefetch(nz, nb, s_bm + tid, [&](uint32_t row) { return tri[(size_t)min(b0 * 32u + row, n_faces - 1u) * 4]; }, eval);
     }
     if (!valid) return;
     float r, g, b;
