@@ -203,15 +203,16 @@ def main():
                          "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
                          "flop_per_test": FLOP_PER_SPHERE_TEST, "kernel_ms": round(k_ms, 3), "launches_per_step": launches,
-                         "note": "achieved = ALGORITHMIC 20 FLOP per ray-sphere test x tests / kernel time; peak = 157.3 TFLOP/s, the f32 peak "
-                                 "of gfx950 (dense f32 MFMA == f32 vector ALU).  The algorithmic work is f32; the kernel executes its "
-                                 "conservative candidate filter as bf16 MFMAs on 3-way split operands (see roofline_mfma_bf16) and the exact f32 "
-                                 "test only on survivors, which is how it can approach the f32 peak"},
+                         "note": "achieved = ALGORITHMIC 20 FLOP per ray-sphere test (SURVEY.md 8d) x tests / kernel time; peak = 157.3 "
+                                 "TFLOP/s, the f32 peak of gfx950 (dense f32 MFMA == f32 vector ALU).  The algorithmic work is f32; the "
+                                 "kernel executes its conservative candidate filter as bf16 MFMAs on 3-way split operands (see "
+                                 "roofline_mfma_bf16) with ONE vector instruction per test and the exact f32 test only on survivors, "
+                                 "which is how frac can exceed 1; what limits the kernel is vector-ALU instruction issue (valu_issue)"},
             "roofline_mfma_bf16": {"bound": "mfma", "achieved": round(st.mfma_instructions * 32768.0 / max(1, launches) / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
                                    "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(st.mfma_instructions * 32768.0 / max(1, launches) / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if k_ms > 0 else 0.0,
                                    "note": "EXECUTED matrix work: v_mfma_f32_32x32x16_bf16 instructions x 32768 FLOP / kernel time vs the dense bf16 peak; "
-                                           "the VALU decodes 2 instructions per (ray, sphere) pair beside it"},
+                                           "the vector ALU turns each result's sign into a candidate bit (1 instruction per pair) beside it"},
             "roofline_hbm": {"bound": "hbm", "achieved": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else 0.0,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5) if k_ms > 0 else 0.0,
@@ -219,6 +220,14 @@ def main():
                              "note": "algorithmic bytes = 16 B radiance record per sample; the 7.7 KB scene streams through the scalar "
                                      "cache; traffic = PMC bytes per launch (profiles/), source of truth for re-reads"},
         }
+        try:                                                     # vector-ALU issue utilisation of the same kernel, from the committed PMC pass
+            busy = pmc["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0 / (pmc["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0)
+            if traffic is not None:
+                out["valu_issue"] = {"frac": round(busy, 3), "valu_instructions": int(pmc["SQ_INSTS_VALU"]["sum_over_dispatches"]),
+                                     "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x busy cycles), profiles/r01_final_bench_pmc_k_trace.json: "
+                                             "the resource the kernel saturates"}
+        except (NameError, KeyError, ZeroDivisionError):
+            pass
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(rt3, cr, mats, cam, args.cpu_seconds)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
