@@ -1734,7 +1734,7 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     // candidate filter on the matrix cores (RT3_NO_MFMA=1 keeps the VALU scan, for A/B runs): the all-in-LDS kernel for sphere
     // scenes of <= 512 spheres, the tiled kernel for everything else
     const bool use_mfma = !getenv("RT3_NO_MFMA");
-    const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax;
+    const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && !getenv("RT3_FORCE_TILED");   // (A/B knob)
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
     const size_t mfma_lds = mfma_single ? (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)kBitmapBytes
                                         : (size_t)16 * 4096 + (size_t)kBitmapBytes;
