@@ -1,0 +1,181 @@
+// rt3_kernel_common.hpp — constants, arithmetic helpers (hash RNG, sky, pixel packing, sin/cos), Mode-X launch arguments and start_path()
+// Part of rt3_device.hip (one translation unit, gfx950 only); included from there, in this order.
+#pragma once
+
+namespace {
+
+constexpr int      kBlock       = 256;     // 4 wavefronts of 64
+constexpr int      kCandSlots   = 16;      // deferred sphere candidates per lane (LDS), flushed when full
+constexpr uint32_t kWorkChunk   = 256;     // samples a wave takes from the global queue per atomic
+constexpr uint32_t kSphLdsMax   = 2048;    // spheres mirrored in LDS for the exact-evaluation gathers (32 KiB)
+constexpr uint32_t kModeRTile   = 512;     // faces per LDS tile in k_mode_r (32 KiB)
+
+// filler for the tail of a sphere tile: r^2 = -1e30 makes the discriminant negative for every ray
+#define kPadSphere make_float4(0.0f, 0.0f, 0.0f, -1e30f)
+
+struct CamDev { float ox, oy, oz, hx, hy, hz, vx, vy, vz, lx, ly, lz; };
+
+// ------------------------------------------------------------------------------------------------------
+// Small device helpers
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// dot3 of SequentialRenderer.cpp:32-33 / glm::dot: unfused, left to right.
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return ax * bx + ay * by + az * bz;
+}
+// Mode-X dot: z*z' + (y*y' + x*x') as two fused multiply-adds.
+__device__ __forceinline__ float dotf(float ax, float ay, float az, float bx, float by, float bz) {
+    return fma_(az, bz, fma_(ay, by, ax * bx));
+}
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of a 64-bit lane mask below the calling lane (exclusive prefix count)
+__device__ __forceinline__ uint32_t prefix_count(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// n / d for a divisor fixed per launch: multiply-high by a precomputed magic (branch-free round-up method of
+// Granlund & Montgomery as used by libdivide); exact for every 32-bit n.  d == 1 is encoded as shift == 0xFFFFFFFF.
+struct FastDiv { uint32_t magic, shift; };
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+    if (f.shift == 0xFFFFFFFFu) return n;                           // wave-uniform
+    const uint32_t q = __umulhi(f.magic, n);
+    return (((n - q) >> 1) + q) >> f.shift;
+}
+
+// random_v1.glsl:22-31, :37-52
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x += x << 10; x ^= x >> 6; x += x << 3; x ^= x >> 11; x += x << 15;
+    return x;
+}
+__device__ __forceinline__ uint32_t hash2(uint32_t a, uint32_t b) { return hash_u32(a ^ hash_u32(b)); }
+__device__ __forceinline__ float u01(uint32_t m) { return __uint_as_float((m & 0x007FFFFFu) | 0x3F800000u) - 1.0f; }
+__device__ __forceinline__ float rnd(uint32_t base, uint32_t ctr) { return u01(hash2(base, ctr)); }
+
+// sky gradient, SequentialRenderer.cpp:105-107 (float form of raytracer_v3.glsl:139-141; same bits)
+__device__ __forceinline__ void sky(float dx, float dy, float dz, float& r, float& g, float& b) {
+    const float len = __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+    const float uy = dy / len;
+    const float t = 0.5f * (uy + 1.0f);
+    const float a = 1.0f - t;
+    r = a * 1.0f + t * 0.5f;
+    g = a * 1.0f + t * 0.7f;
+    b = a * 1.0f + t * 1.0f;
+}
+// glm::packUnorm4x8(vec4(1, b, g, r)), glm/detail/func_packing.inl:67-83
+__device__ __forceinline__ uint32_t pack_channel(float c) {
+    float m = c < 0.0f ? 0.0f : c;
+    m = 1.0f < m ? 1.0f : m;
+    return (uint32_t)(__builtin_roundf(m * 255.0f)) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t pack_pixel(float r, float g, float b) {
+    return 0xFFu | (pack_channel(b) << 8) | (pack_channel(g) << 16) | (pack_channel(r) << 24);
+}
+
+// (cos, sin)(2*pi*u), u in [0,1): quadrant + Taylor/Horner in fma
+__device__ __forceinline__ void sincos2pi(float u, float& c_out, float& s_out) {
+    const float a = u * 4.0f;
+    const int k = (int)a;
+    const float f = a - (float)k;
+    const float x = f * 1.57079637f;
+    const float x2 = x * x;
+    float p = fma_(x2, -2.50521084e-8f, 2.75573192e-6f);
+    p = fma_(x2, p, -1.98412698e-4f);
+    p = fma_(x2, p, 8.33333333e-3f);
+    p = fma_(x2, p, -1.66666667e-1f);
+    const float s = fma_(x * x2, p, x);
+    float q = fma_(x2, 2.08767570e-9f, -2.75573192e-7f);
+    q = fma_(x2, q, 2.48015873e-5f);
+    q = fma_(x2, q, -1.38888889e-3f);
+    q = fma_(x2, q, 4.16666667e-2f);
+    q = fma_(x2, q, -0.5f);
+    const float c = fma_(x2, q, 1.0f);
+    const int kk = k & 3;
+    c_out = kk == 0 ? c : kk == 1 ? -s : kk == 2 ? -c : s;
+    s_out = kk == 0 ? s : kk == 1 ? c : kk == 2 ? -s : -c;
+}
+__device__ __forceinline__ void unit_vector(float xi0, float xi1, float& x, float& y, float& z) {
+    z = fma_(-2.0f, xi0, 1.0f);
+    const float rr = fma_(-z, z, 1.0f);
+    const float r = __builtin_sqrtf(rr > 0.0f ? rr : 0.0f);
+    float c, s;
+    sincos2pi(xi1, c, s);
+    x = r * c;
+    y = r * s;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Mode X
+// ------------------------------------------------------------------------------------------------------
+struct TraceArgs {
+    const float4* sph;       const float* sph_invr;  const float4* sph_mat;  const uint32_t* sph_kind;  uint32_t n_sph;
+    const float4* tri;       const float4* tri_mat;  const uint32_t* tri_kind;  const float4* tri_bound; uint32_t n_tri;
+    CamDev cam;
+    float lens_radius, lux, luy, luz, lvx, lvy, lvz;
+    uint32_t width, height, spp, max_depth, seed, flags, edge;
+    FastDiv div_npix, div_width, div_edge, div_tile_rows;
+    float t_min;
+    uint32_t tile_rows, tile_index, tile_count;
+    uint32_t npix;           // pixels owned by this shard
+    uint32_t s0;             // first sample of this batch
+    uint32_t total;          // npix * samples in this batch
+    float4* rad;             // per-sample radiance, [sample in batch][owned pixel]
+    uint32_t* work_counter;
+    unsigned long long* cast_counter;
+};
+
+struct Path {
+    float ox, oy, oz, dx, dy, dz;
+    float tr, tg, tb, lr, lg, lb;
+    uint32_t slot, base, depth;
+};
+
+__device__ __forceinline__ uint32_t frame_row(const TraceArgs& A, uint32_t local_row) {
+    if (A.tile_count <= 1) return local_row;
+    const uint32_t lb = fdiv(local_row, A.div_tile_rows), in = local_row - lb * A.tile_rows;
+    return (lb * A.tile_count + A.tile_index) * A.tile_rows + in;
+}
+
+// sample -> primary ray (raytracer_v4.glsl:190-214 with the jitter in pixel units), unit direction
+__device__ __forceinline__ void start_path(const TraceArgs& A, uint32_t item, Path& P) {
+    const uint32_t sb = fdiv(item, A.div_npix), pix = item - sb * A.npix;
+    const uint32_t s = A.s0 + sb;
+    const uint32_t lrow = fdiv(pix, A.div_width), x = pix - lrow * A.width;
+    const uint32_t y = frame_row(A, lrow);
+    const uint32_t base = hash2(y * A.width + x, hash2(s, A.seed));
+    float jx = 0.0f, jy = 0.0f;
+    if (A.spp > 1) {
+        const float xi0 = rnd(base, 1), xi1 = rnd(base, 2);
+        if (A.edge != 0) {
+            const uint32_t sy = fdiv(s, A.div_edge), sx = s - sy * A.edge;
+            jx = ((float)sx + xi0) / (float)A.edge - 0.5f;
+            jy = ((float)sy + xi1) / (float)A.edge - 0.5f;
+        } else { jx = xi0 - 0.5f; jy = xi1 - 0.5f; }
+    }
+    const float u = ((float)x + jx) / ((float)A.width - 1.0f);
+    const float v = ((float)(A.height - 1 - y) + jy) / ((float)A.height - 1.0f);
+    const CamDev& c = A.cam;
+    float rx = ((c.lx + u * c.hx) + v * c.vx) - c.ox;
+    float ry = ((c.ly + u * c.hy) + v * c.vy) - c.oy;
+    float rz = ((c.lz + u * c.hz) + v * c.vz) - c.oz;
+    float ox = c.ox, oy = c.oy, oz = c.oz;
+    if (A.lens_radius > 0.0f) {
+        const float xi2 = rnd(base, 3), xi3 = rnd(base, 4);
+        const float r = A.lens_radius * __builtin_sqrtf(xi2);
+        float cs, sn;
+        sincos2pi(xi3, cs, sn);
+        const float a = r * cs, b = r * sn;
+        const float fx = a * A.lux + b * A.lvx, fy = a * A.luy + b * A.lvy, fz = a * A.luz + b * A.lvz;
+        ox = ox + fx; oy = oy + fy; oz = oz + fz;
+        rx = rx - fx; ry = ry - fy; rz = rz - fz;
+    }
+    const float inv = 1.0f / __builtin_sqrtf(dot3(rx, ry, rz, rx, ry, rz));
+    P.ox = ox; P.oy = oy; P.oz = oz;
+    P.dx = rx * inv; P.dy = ry * inv; P.dz = rz * inv;
+    P.tr = P.tg = P.tb = 1.0f;
+    P.lr = P.lg = P.lb = 0.0f;
+    P.slot = item; P.base = base; P.depth = 0;
+}
+
+}  // namespace

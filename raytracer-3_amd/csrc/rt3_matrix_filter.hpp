@@ -1,0 +1,452 @@
+// rt3_matrix_filter.hpp — the candidate filter on the matrix cores and its kernels: k_trace_mfma, k_trace_mfma_tiled, k_mode_r_mfma
+// Part of rt3_device.hip (one translation unit, gfx950 only); included from there, in this order.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// The candidate filter on the MATRIX cores
+// ------------------------------------------------------------------------------------------------------
+// For a unit direction d the discriminant of every (sphere, ray) pair is ONE dense contraction of 11 bilinear terms:
+//     disc_ij = (d_i.(C_j - o_i))^2 - |C_j - o_i|^2 + r_j^2
+//             = sum_{a<=b} (d_a d_b [x2 if a != b]) (C_a C_b)  +  sum_a (2 o_a - 2 (o.d) d_a) C_a  +  1 K_j  +  E_i 1
+//     K_j = (r_j^2 - |C_j|^2) + eps (|C_j|^2 + r_j^2),    E_i = (o.d)^2 - |o|^2 (1 - eps)
+// i.e. disc + margin with margin_ij = eps (|C_j|^2 + r_j^2 + |o_i|^2).  It runs on v_mfma_f32_32x32x16_bf16 with every f32 factor
+// split into three bf16 parts (x = H + M + L) and the six leading cross products (HH, HM, MH, HL, LH, MM) laid out along K:
+// 9 x 6 + 3 + 3 = 60 of the 64 K-slots of four chained MFMAs, so the accumulator holds the margin-inflated discriminant itself and
+// its SIGN BIT is the candidate flag — one v_alignbit per pair on the vector ALU instead of the 10 instructions of the scalar test.
+// The expanded form cancels catastrophically and is therefore used ONLY as a conservative filter: eps = 2e-5 covers its error
+// (measured <= 0.05 eps (|C|^2 + r^2 + |o|^2) in tools/filter_model.py's pessimistic model) twenty times over, and the surviving
+// pairs go through the same exact f32 evaluation as in k_trace, so images stay bit-identical.
+// A = spheres (rows), B = rays (columns): lane l holds, for ray (l & 31) of the current column set, 16 results in its accumulator
+// registers (rows (g&3) + 8(g>>2) + 4(l>>5)).  Spheres are assigned to rows so that accumulator register g of lane half w is sphere
+// 16 w + 15 - g of the row block: after one v_permlane32_swap every lane owns the 32-bit candidate word of ITS OWN ray for the
+// block, bit b <-> sphere 32 blk + b, which it parks in a lane-private LDS column until the exact tests run.
+constexpr int      kMB        = 1024;      // threads per workgroup of the matrix-filter kernels (one workgroup per CU, 4 waves per SIMD)
+constexpr uint32_t kMfmaSphMax = 512;      // 16 row blocks x 4 operand fragments x 1 KiB = 64 KiB of LDS
+constexpr uint32_t kBitmapBytes = 16 * kMB * 4;   // candidate words: [16 row blocks][kMB lanes]
+constexpr float    kFilterEps = 2e-5f;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// K-slot layout.  Operand q (0..3) of the chain holds 16 K-elements, lane half hh supplies elements 8 hh .. 8 hh + 7 as four
+// dwords i = 0..3 of two bf16 each.  With x_t / y_t the ray / sphere factor of term t (t = 0..8), E and K the two constants:
+//     (q = 0,1,2; hh = 0)  ray (H x_2i, H x_2i+1)                      sphere (P y_2i, P y_2i+1),  P = H, M, L for q = 0, 1, 2
+//     (q = 0,1;   hh = 1)  ray (M x_2i, M x_2i+1)                      sphere (P y_2i, P y_2i+1),  P = H, M
+//     (q = 2;     hh = 1)  ray (L x_2i, L x_2i+1)                      sphere (H y_2i, H y_2i+1)
+//     (q = 3;     hh = 0)  ray (H x_8, 1) x3, (M x_8, H E)             sphere (H y_8, H K), (M y_8, M K), (L y_8, L K), (H y_8, 1)
+//     (q = 3;     hh = 1)  ray (M x_8, M E), (L x_8, L E), 0, 0        sphere (M y_8, 1), (H y_8, 1), 0, 0
+// so a lane needs only three distinct ray-side register quads per column set (operands 0 and 1 share one).
+// row of the A operand that holds sphere b (0..31) of a row block
+__host__ __device__ constexpr uint32_t frag_row_of(uint32_t b) { return ((15u - (b & 15u)) & 3u) + 8u * ((15u - (b & 15u)) >> 2) + 4u * (b >> 4); }
+
+__host__ __device__ inline uint32_t bf16_rn(float x) {            // round to nearest even, finite inputs
+    uint32_t u = __builtin_bit_cast(uint32_t, x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__host__ __device__ inline float bf16_up(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+__host__ __device__ inline void split3(float x, uint32_t* parts /*[3]*/) {
+    parts[0] = bf16_rn(x);
+    const float r1 = x - bf16_up(parts[0]);
+    parts[1] = bf16_rn(r1);
+    parts[2] = bf16_rn(r1 - bf16_up(parts[1]));
+}
+
+// Sphere-side (A operand) fragment of one bounding sphere: out[q][hh][dword] = K elements 8 hh .. 8 hh + 7 of MFMA operand q.
+// kj = filter_kj(|C|^2, r^2); a padding row uses C = 0, kj = -1e30 (never a candidate), an unbounded one kj = +1e30 (always).
+__host__ __device__ inline void bound_frag_row(float cx, float cy, float cz, float kj, uint32_t out[4][2][4]) {
+    uint32_t y[9][3], k[3];                                         // [term][part]
+    const double x = cx, yy = cy, z = cz;
+    split3((float)(x * x), y[0]); split3((float)(yy * yy), y[1]); split3((float)(z * z), y[2]);
+    split3((float)(x * yy), y[3]); split3((float)(x * z), y[4]); split3((float)(yy * z), y[5]);
+    split3(cx, y[6]); split3(cy, y[7]); split3(cz, y[8]);
+    split3(kj, k);
+    const uint32_t one = 0x3F80u;
+    auto pk = [](uint32_t lo, uint32_t hi) { return lo | (hi << 16); };
+    for (int i = 0; i < 4; i++) {
+        for (int q = 0; q < 3; q++) out[q][0][i] = pk(y[2 * i][q], y[2 * i + 1][q]);
+        for (int q = 0; q < 2; q++) out[q][1][i] = pk(y[2 * i][q], y[2 * i + 1][q]);
+        out[2][1][i] = pk(y[2 * i][0], y[2 * i + 1][0]);
+    }
+    for (int i = 0; i < 3; i++) out[3][0][i] = pk(y[8][i], k[i]);
+    out[3][0][3] = pk(y[8][0], one);
+    out[3][1][0] = pk(y[8][1], one);
+    out[3][1][1] = pk(y[8][0], one);
+    out[3][1][2] = 0u; out[3][1][3] = 0u;
+}
+__host__ __device__ inline float filter_kj(double c2, double r2) { return (float)((r2 - c2) + (double)kFilterEps * (c2 + r2)); }
+constexpr float kNeverCandidate = -1e30f, kAlwaysCandidate = 1e30f;
+
+// Ray-side (B operand) fragments of the 64 rays of a wave: [column set (rays 0..31 / 32..63)][operands 0 and 1, operand 2, operand 3].
+struct RayOperands { u32x4 b[2][3]; };
+// v_cvt_pk_bf16_f32 (round to nearest even, two floats -> one dword).  HARDWARE NOTE (measured on MI355X, ROCm 7.2): a VALU
+// instruction that consumes the result straight after the conversion can read a stale register — about one ray in 10^6 lost a
+// candidate, differently in every run, until wait states were added; hipcc's hazard recognizer inserts none for this opcode
+// (it does for v_permlane32_swap).  The conversion is therefore issued through inline asm with its own `s_nop 3`, which also
+// covers the two wait states a following v_permlane32_swap needs.  tests/test_gpu_repeatability.py guards the property.
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 3" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// v_permlane32_swap(x, y): x's upper half-wave <-> y's lower half-wave; set0 = new x, set1 = new y
+__device__ __forceinline__ void swap32(uint32_t x, uint32_t y, uint32_t& set0, uint32_t& set1) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    set0 = r[0]; set1 = r[1];
+}
+__device__ __forceinline__ float pk_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float pk_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
+__device__ __forceinline__ void build_ray_operands(float ox, float oy, float oz, float dx, float dy, float dz, bool alive, RayOperands& R) {
+    const float od = dotf(ox, oy, oz, dx, dy, dz), oo = dotf(ox, oy, oz, ox, oy, oz);
+    float x[9] = { dx * dx, dy * dy, dz * dz, 2.0f * dx * dy, 2.0f * dx * dz, 2.0f * dy * dz,
+                   2.0f * (ox - od * dx), 2.0f * (oy - od * dy), 2.0f * (oz - od * dz) };
+    float e = alive ? od * od - oo * (1.0f - kFilterEps) : -3e30f;      // a dead lane's column can never produce a candidate
+    // three-way bf16 split of the ten factors, two at a time: part = cvt_pk(residuals), residual -= part
+    uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ph[i] = pk_bf16(x[2 * i], x[2 * i + 1]); x[2 * i] -= pk_lo(ph[i]); x[2 * i + 1] -= pk_hi(ph[i]); }
+    const uint32_t h8 = pk_bf16(x[8], 1.0f);
+    x[8] -= pk_lo(h8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { pm[i] = pk_bf16(x[2 * i], x[2 * i + 1]); x[2 * i] -= pk_lo(pm[i]); x[2 * i + 1] -= pk_hi(pm[i]); }
+    const uint32_t m8a = pk_bf16(x[8], e);
+    e -= pk_hi(m8a);
+    const uint32_t m8b = pk_bf16(x[8], e);
+    e -= pk_hi(m8b);
+    x[8] -= pk_lo(m8a);
+#pragma unroll
+    for (int i = 0; i < 4; i++) pl[i] = pk_bf16(x[2 * i], x[2 * i + 1]);
+    const uint32_t l8 = pk_bf16(x[8], e);
+    // Lane (w, col) supplies elements 8 w .. 8 w + 7 of ray 32 S + col for column set S: lanes 0-31 keep their hh = 0 dwords for
+    // set 0 and need their partner's for set 1, lanes 32-63 the mirror image with hh = 1 — v_permlane32_swap(a, b) exchanges a's
+    // upper half with b's lower half, so swapping an (hh = 0 dword, hh = 1 dword) pair leaves the set-0 dword in a, set 1 in b.
+    uint32_t s0[3][4], s1[3][4];
+    const uint32_t lo3[4] = { h8, h8, h8, m8a }, hi3[4] = { m8b, l8, 0u, 0u };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        swap32(ph[i], pm[i], s0[0][i], s1[0][i]);
+        swap32(ph[i], pl[i], s0[1][i], s1[1][i]);
+        swap32(lo3[i], hi3[i], s0[2][i], s1[2][i]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        R.b[0][k] = u32x4{ s0[k][0], s0[k][1], s0[k][2], s0[k][3] };
+        R.b[1][k] = u32x4{ s1[k][0], s1[k][1], s1[k][2], s1[k][3] };
+    }
+}
+
+// The matrix-core scan of one LDS-resident tile of up to 16 row blocks (512 bounding spheres) against the 64 rays of the wave:
+// per row block 8 MFMAs, 32 v_alignbit and one exchange.  Candidate word `blk` of this lane's ray goes to bm[blk * kMB] (bit b
+// CLEAR <-> sphere 32 blk + b is a candidate); the return value has bit blk set when that word holds any candidate.
+__device__ __forceinline__ uint32_t mfma_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands& R, uint32_t* bm, uint32_t lane) {
+    uint32_t nz = 0;                                                // block blk -> bit n_blocks - 1 - blk
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {                 // four row blocks per trip: their LDS offsets are immediates
+        const u32x4* fr0 = s_frag + (size_t)b0 * 256 + lane;
+        uint32_t* bm0 = bm + b0 * kMB;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            if (b0 + u >= n_blocks) break;
+            const u32x4* fr = fr0 + u * 256;
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
+            const f32x16 zero = { 0 };
+            f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[0][0]), zero, 0, 0, 0);
+            f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[1][0]), zero, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[0][0]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[1][0]), d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[0][1]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[1][1]), d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[0][2]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[1][2]), d1, 0, 0, 0);
+            uint32_t n0 = 0xFFFFFFFFu, n1 = 0xFFFFFFFFu;           // sign bits: register g -> bit 15 - g
+#pragma unroll
+            for (int g = 0; g < 16; g++) n0 = __builtin_amdgcn_alignbit(n0, __float_as_uint(d0[g]), 31);
+#pragma unroll
+            for (int g = 0; g < 16; g++) n1 = __builtin_amdgcn_alignbit(n1, __float_as_uint(d1[g]), 31);
+            // lower lanes: own set-0 signs (rows of half 0) + the partner's set-0 signs (rows of half 1); upper lanes: set 1
+            const auto sw = __builtin_amdgcn_permlane32_swap(n0, n1, false, false);
+            const uint32_t w = __builtin_amdgcn_perm(sw[1], sw[0], 0x05040100u);
+            bm0[u * kMB] = w;
+            // nz = 2 nz + (w != ~0): compare into VCC, add with carry (the two wait states between a VALU write of VCC and a
+            // VALU read of it are what hipcc itself inserts on gfx950)
+            asm("v_cmp_ne_u32_e32 vcc, -1, %1\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(nz) : "v"(w) : "vcc");
+        }
+    }
+    return nz;
+}
+
+// Exact tests of the parked candidates of this lane's ray, in ascending sphere order.
+struct CandIter { uint32_t nz, bits, blk, nb; };
+__device__ __forceinline__ bool cand_next(CandIter& it, const uint32_t* bm, uint32_t& row) {
+    if (it.bits == 0u) {
+        if (it.nz == 0u) return false;
+        const uint32_t hb = 31u - (uint32_t)__builtin_clz(it.nz);
+        it.blk = it.nb - 1u - hb;
+        it.nz ^= 1u << hb;
+        it.bits = ~bm[it.blk * kMB];                                // non-zero: the scan set this word's nz bit
+    }
+    row = it.blk * 32u + (uint32_t)__builtin_ctz(it.bits);
+    it.bits &= it.bits - 1u;
+    return true;
+}
+template <class Eval>
+__device__ __forceinline__ void mfma_flush(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, Eval&& eval) {
+    CandIter it = { nz, 0u, 0u, n_blocks };
+    uint32_t row;
+    while (cand_next(it, bm, row)) eval(row);
+}
+// Same, for exact tests that gather from global memory: `fetch(row)` (the first 16 bytes of the record) is issued one
+// candidate ahead of `eval(row, record)`.
+template <class Fetch, class Eval>
+__device__ __forceinline__ void mfma_flush_prefetch(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, Fetch&& fetch, Eval&& eval) {
+    CandIter it = { nz, 0u, 0u, n_blocks };
+    uint32_t row = 0, rown = 0;
+    bool have = cand_next(it, bm, row);
+    float4 rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f), recn = rec;
+    if (have) rec = fetch(row);
+    while (have) {
+        const bool haven = cand_next(it, bm, rown);
+        if (haven) recn = fetch(rown);
+        eval(row, rec);
+        row = rown; rec = recn; have = haven;
+    }
+}
+
+// The reference's plane + three-edge test of one face (same operations, same order as k_trace's face evaluation); returns t or NaN.
+__device__ __forceinline__ bool face_hit(const float4 n, const float4* __restrict__ f, float ox, float oy, float oz, float dx, float dy, float dz,
+                                         float t_lo, float t_hi, float& t_out) {
+    const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
+    if (nd == 0.0f) return false;
+    const float t = (n.w - dot3(n.x, n.y, n.z, ox, oy, oz)) / nd;
+    if (!(t >= t_lo && t <= t_hi)) return false;
+    const float4 p1 = f[1], p2 = f[2], p3 = f[3];
+    const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+    float ex, ey, ez, qx, qy, qz, cx, cy, cz;
+    ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
+    ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
+    ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
+    t_out = t;
+    return true;
+}
+
+// Sphere scenes of <= 512 spheres: everything the loop touches lives in LDS, waves never synchronise after the prologue.
+__global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32x4* __restrict__ frags, uint32_t n_blocks) {
+    extern __shared__ u32x4 lds_dyn[];
+    u32x4* s_frag = lds_dyn;                                                   // [n_blocks][4][64]
+    float4* s_sph = reinterpret_cast<float4*>(s_frag + (size_t)n_blocks * 256);   // [n_blocks * 32] (cx, cy, cz, r^2) for the exact test
+    float4* s_mat = s_sph + (size_t)n_blocks * 32;                               // materials, kinds, 1/r: read at every hit
+    float* s_invr = reinterpret_cast<float*>(s_mat + (size_t)n_blocks * 32);
+    uint32_t* s_kind = reinterpret_cast<uint32_t*>(s_invr + (size_t)n_blocks * 32);
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_kind + (size_t)n_blocks * 32); // [16][kMB] candidate words
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    for (uint32_t k = tid; k < n_blocks * 256; k += kMB) s_frag[k] = frags[k];
+    for (uint32_t k = tid; k < n_blocks * 32; k += kMB) {
+        const bool in = k < A.n_sph;
+        s_sph[k] = in ? A.sph[k] : kPadSphere;
+        s_mat[k] = in ? A.sph_mat[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_invr[k] = in ? A.sph_invr[k] : 0.0f;
+        s_kind[k] = in ? A.sph_kind[k] : 0u;
+    }
+    __syncthreads();                                                            // the only barrier
+
+    Path P;
+    P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
+    P.tr = P.tg = P.tb = 0.0f; P.lr = P.lg = P.lb = 0.0f; P.slot = 0; P.base = 0; P.depth = 0;
+    bool alive = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    RayStock Q;
+    Q.ox = Q.oy = Q.oz = 0.0f; Q.dx = Q.dy = 0.0f; Q.dz = 1.0f; Q.slot = 0; Q.base = 0; Q.n = 0;
+    unsigned long long casts = 0, iters = 0;
+#ifdef RT3_PROFILE
+    unsigned long long prof_flush_iters = 0, prof_cands = 0, prof_refills = 0;
+#endif
+
+    for (;;) {
+        refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
+        const unsigned long long live = __ballot(alive);
+        if (live == 0ull) break;
+        casts += (unsigned long long)__popcll(live);
+        iters++;
+        const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+        RayOperands R;
+        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, R);
+
+        // nearest hit: exact evaluation of queued candidates (ties: lower sphere index, as the sequential loop)
+        float tbest = __builtin_inff();
+        uint32_t ibest = 0, kind = 0;
+        auto eval = [&](uint32_t j) {
+            const float4 s = s_sph[j];
+            const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+            const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+            const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+            const float disc = fma_(h, h, -c);
+            if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return;
+            const float sq = __builtin_sqrtf(disc);
+            float t = h - sq;
+            if (!(t > A.t_min)) t = h + sq;
+            if (t > A.t_min && (t < tbest || (t == tbest && j < ibest))) { tbest = t; ibest = j; kind = 2; }
+        };
+        const uint32_t nz = mfma_scan_tile(s_frag, n_blocks, R, s_bm + tid, lane);
+#ifdef RT3_PROFILE
+        {
+            uint32_t mine = 0;
+            CandIter it = { nz, 0u, 0u, n_blocks };
+            uint32_t row;
+            while (cand_next(it, s_bm + tid, row)) mine++;
+            uint32_t mx = mine, sm = mine;
+            for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sm += (uint32_t)__shfl_xor((int)sm, o); }
+            prof_flush_iters += mx; prof_cands += sm;
+            prof_refills += (uint32_t)__popcll(__ballot(P.depth == 0 && alive));
+        }
+#endif
+        mfma_flush(nz, n_blocks, s_bm + tid, eval);
+        shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
+    }
+    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
+#ifdef RT3_PROFILE
+    if (lane == 0) { atomicAdd(A.cast_counter + 2, prof_flush_iters); atomicAdd(A.cast_counter + 3, prof_cands); atomicAdd(A.cast_counter + 4, iters); atomicAdd(A.cast_counter + 5, prof_refills); }
+#endif
+}
+
+// Any scene: faces (through their bounding spheres) and spheres, streamed through LDS in tiles of 512 rows.  The 16 waves of the
+// workgroup move through the tiles together (two barriers per tile); the exact tests gather their records from global memory.
+// Ties resolve as in the sequential loops: faces before spheres, then the lower index.
+template <bool HAS_TRI, bool HAS_SPH>
+__global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
+    extern __shared__ u32x4 lds_dyn[];
+    u32x4* s_frag = lds_dyn;                                                   // [16][4][64]
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);           // [16][kMB] candidate words
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+
+    Path P;
+    P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
+    P.tr = P.tg = P.tb = 0.0f; P.lr = P.lg = P.lb = 0.0f; P.slot = 0; P.base = 0; P.depth = 0;
+    bool alive = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    RayStock Q;
+    Q.ox = Q.oy = Q.oz = 0.0f; Q.dx = Q.dy = 0.0f; Q.dz = 1.0f; Q.slot = 0; Q.base = 0; Q.n = 0;
+    unsigned long long casts = 0, mfmas = 0;
+
+    for (;;) {
+        refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
+        const unsigned long long live = __ballot(alive);
+        if (!__syncthreads_or(live != 0ull ? 1 : 0)) break;                      // the workgroup ends together
+        casts += (unsigned long long)__popcll(live);
+        const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+        RayOperands R;
+        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, R);
+        float tbest = __builtin_inff();
+        uint32_t ibest = 0, kind = 0;
+
+        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& fetch_row, auto&& eval_row) {
+            const uint32_t total_blocks = (n_rows + 31u) / 32u;
+            for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
+                const uint32_t nb = min(16u, total_blocks - b0);
+                __syncthreads();                                                // every wave is done with the previous tile
+                for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = frags[(size_t)b0 * 256 + k];
+                __syncthreads();
+                const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
+                mfma_flush_prefetch(nz, nb, s_bm + tid, [&](uint32_t row) { return fetch_row(b0 * 32u + row); },
+                                    [&](uint32_t row, const float4 rec) { eval_row(b0 * 32u + row, rec); });
+                mfmas += nb * 8ull;
+            }
+        };
+        if (HAS_TRI)
+            pass(tri_frags, A.n_tri, [&](uint32_t j) { return A.tri[(size_t)min(j, A.n_tri - 1u) * 4]; }, [&](uint32_t j, const float4 n) {
+                if (j >= A.n_tri) return;
+                float t;
+                if (!face_hit(n, A.tri + (size_t)j * 4, ox, oy, oz, dx, dy, dz, A.t_min, tbest, t)) return;
+                if (t < tbest || j < ibest) { tbest = t; ibest = j; kind = 1; }      // t <= tbest here: equal t keeps the lower face index
+            });
+        if (HAS_SPH)
+            pass(sph_frags, A.n_sph, [&](uint32_t j) { return A.sph[min(j, A.n_sph - 1u)]; }, [&](uint32_t j, const float4 s) {
+                if (j >= A.n_sph) return;
+                const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+                const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+                const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+                const float disc = fma_(h, h, -c);
+                if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return;
+                const float sq = __builtin_sqrtf(disc);
+                float t = h - sq;
+                if (!(t > A.t_min)) t = h + sq;
+                if (t > A.t_min && (t < tbest || (t == tbest && kind == 2 && j < ibest))) { tbest = t; ibest = j; kind = 2; }
+            });
+        shade_lane<HAS_TRI, HAS_SPH>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
+    }
+    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, mfmas); }
+}
+
+// Mode R through the matrix-core filter (camera at the origin, as k_mode_r_fast): one thread per pixel, 1024 pixels per
+// workgroup, face bounding spheres streamed through LDS in tiles of 512; the reference's literal test runs on the candidates.
+__global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ tri, const u32x4* __restrict__ tri_frags,
+                                                    const float4* __restrict__ face_rgb, uint32_t n_faces, CamDev cam,
+                                                    uint32_t width, uint32_t height, uint32_t* __restrict__ out) {
+    extern __shared__ u32x4 lds_dyn[];
+    u32x4* s_frag = lds_dyn;
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    const uint32_t pixel = blockIdx.x * kMB + tid;
+    const bool valid = pixel < width * height;
+    const uint32_t x = valid ? pixel % width : 0u, y = valid ? pixel / width : 0u;
+    const float u = (float)((double)(float)x / ((double)(float)width - 1.0));
+    const float v = (float)((double)(float)(height - 1 - y) / ((double)(float)height - 1.0));
+    const float ox = cam.ox, oy = cam.oy, oz = cam.oz;              // all zero (checked by the host)
+    const float dx = ((cam.lx + u * cam.hx) + v * cam.vx) - ox;
+    const float dy = ((cam.ly + u * cam.hy) + v * cam.vy) - oy;
+    const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
+    const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));     // unit direction for the filter only
+    RayOperands R;
+    build_ray_operands(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid, R);
+
+    uint32_t min_i = 0;
+    float min_t = __builtin_inff();
+    const uint32_t total_blocks = (n_faces + 31u) / 32u;
+    for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
+        const uint32_t nb = min(16u, total_blocks - b0);
+        __syncthreads();
+        for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = tri_frags[(size_t)b0 * 256 + k];
+        __syncthreads();
+        auto eval = [&](uint32_t row, const float4 n) {
+            const uint32_t j = b0 * 32u + row;
+            if (j >= n_faces) return;
+            const float4* f = tri + (size_t)j * 4;
+            const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);       // SequentialRenderer.cpp:56
+            if (nd == 0.0f) return;
+            const float t = (dot3(n.x, n.y, n.z, ox, oy, oz) + n.w) / nd;      // :70
+            if (t < 0.0f || t > min_t) return;                      // :71, with equality kept for the index rule below
+            const float4 p1 = f[1], p2 = f[2], p3 = f[3];
+            const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+            float ex, ey, ez, qx, qy, qz, cx, cy, cz;
+            ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
+            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
+            if (t < min_t || j < min_i) { min_i = j; min_t = t; }   // "t >= min_t rejects" of :71 == the lowest index wins ties
+        };
+        const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
+        mfma_flush_prefetch(nz, nb, s_bm + tid, [&](uint32_t row) { return tri[(size_t)min(b0 * 32u + row, n_faces - 1u) * 4]; }, eval);
+    }
+    if (!valid) return;
+    float r, g, b;
+    if (min_t < __builtin_inff()) { const float4 c = face_rgb[min_i]; r = c.x; g = c.y; b = c.z; }
+    else sky(dx, dy, dz, r, g, b);
+    out[pixel] = pack_pixel(r, g, b);
+}
+
+}  // namespace

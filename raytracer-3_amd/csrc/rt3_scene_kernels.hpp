@@ -1,0 +1,122 @@
+// rt3_scene_kernels.hpp — device-side scene assembly: tessellated spheres and the merge into the render layout (k_commit_mesh)
+// Part of rt3_device.hip (one translation unit, gfx950 only); included from there, in this order.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// Device-side scene assembly: HIP equivalents of the reference's pre-render shaders and of the merge
+// ------------------------------------------------------------------------------------------------------
+struct SphereGen { float cx, cy, cz, radius; uint32_t m, p; float r, g, b; uint32_t face_offset, vertex_offset; };
+
+// compute_point (Sphere.cpp:69-79 / pre_render_sphere_v2_vertices.glsl:77-83).  The CPU form is followed (double
+// trig on a float ratio, rounded to float per component), not the shader's float trig, so that a device-tessellated
+// sphere equals a host-tessellated one.
+__device__ __forceinline__ float4 sphere_point(const SphereGen& s, float fx, float fy) {
+    const double ty = M_PI * (double)(fy / (float)(s.p - 1));
+    const double tx = 2 * M_PI * (double)(fx / (float)s.m);
+    const float ux = (float)(sin(ty) * cos(tx)), uy = (float)cos(ty), uz = (float)(sin(ty) * sin(tx));
+    return make_float4(s.cx + s.radius * ux, s.cy + s.radius * uy, s.cz + s.radius * uz, 0.0f);
+}
+
+// pre_render_sphere_v2_vertices.glsl:88-113: one thread per (meridian x, parallel y)
+__global__ void k_prerender_sphere_vertices(SphereGen s, float4* __restrict__ verts) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x == 0 && y == 0) verts[s.vertex_offset] = sphere_point(s, 0.0f, 0.0f);
+    else if (x < s.m && y > 0 && y < s.p - 1) verts[s.vertex_offset + 1 + (y - 1) * s.m + x] = sphere_point(s, (float)x, (float)y);
+    else if (x == 0 && y == s.p - 1) verts[s.vertex_offset + 1 + (y - 1) * s.m] = sphere_point(s, 0.0f, (float)y);
+}
+
+__device__ __forceinline__ void store_face(rt3_gface* f, uint32_t a, uint32_t b, uint32_t c, float4 pa, float4 pb, float4 pc,
+                                           const SphereGen& s) {
+    // normal = normalize(cross(c - a, b - a)) with glm's evaluation order; colour = colour * |n . (0,0,-1)| (Sphere.cpp:153-155)
+    const float ex = pc.x - pa.x, ey = pc.y - pa.y, ez = pc.z - pa.z, fx = pb.x - pa.x, fy = pb.y - pa.y, fz = pb.z - pa.z;
+    const float nx = ey * fz - fy * ez, ny = ez * fx - fz * ex, nz = ex * fy - fx * ey;
+    const float inv = 1.0f / __builtin_sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+    const float ux = nx * inv, uy = ny * inv, uz = nz * inv;
+    const float shade = __builtin_fabsf(ux * 0.0f + uy * 0.0f + uz * -1.0f);
+    f->v1 = a; f->v2 = b; f->v3 = c; f->_pad0 = 0;
+    f->normal[0] = ux; f->normal[1] = uy; f->normal[2] = uz; f->_pad1 = 0;
+    f->color[0] = s.r * shade; f->color[1] = s.g * shade; f->color[2] = s.b * shade; f->_pad2 = 0;
+}
+
+// pre_render_sphere_v2_faces.glsl:83-194: one thread per (x, y >= 1); reads the vertices the first kernel wrote
+__global__ void k_prerender_sphere_faces(SphereGen s, rt3_gface* __restrict__ faces, const float4* __restrict__ verts) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y + 1;
+    if (x >= s.m || y >= s.p) return;
+    const uint32_t xm1 = x > 0 ? x - 1 : s.m - 1, vo = s.vertex_offset;
+    rt3_gface* out = faces + s.face_offset;
+    if (y == 1) {
+        const uint32_t a = vo, b = vo + 1 + xm1, c = vo + 1 + x;
+        store_face(out + x, a, b, c, verts[a], verts[b], verts[c], s);
+    } else if (y < s.p - 1) {
+        const uint32_t base = s.m + 2 * (y - 2) * s.m;
+        const uint32_t p1 = vo + 1 + (y - 2) * s.m + xm1, p2 = vo + 1 + (y - 2) * s.m + x;
+        const uint32_t p3 = vo + 1 + (y - 1) * s.m + xm1, p4 = vo + 1 + (y - 1) * s.m + x;
+        store_face(out + base + 2 * x, p1, p3, p4, verts[p1], verts[p3], verts[p4], s);
+        store_face(out + base + 2 * x + 1, p1, p2, p4, verts[p1], verts[p2], verts[p4], s);
+    } else {
+        const uint32_t base = s.m + 2 * (y - 2) * s.m;
+        const uint32_t a = vo + 1 + (y - 1) * s.m, b = vo + 1 + (y - 2) * s.m + xm1, c = vo + 1 + (y - 2) * s.m + x;
+        store_face(out + base + x, a, b, c, verts[a], verts[b], verts[c], s);
+    }
+}
+
+// De-indexes the merged GFace[] / vec4[] into what the render kernels read: 4 float4 per face (n + plane distance, p1, p2,
+// p3), the bounding sphere of §5.1, the material.  Entries [n_faces, n_pad) of `bound` become never-hit records.
+__global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4* __restrict__ verts, uint32_t n_faces, uint32_t n_pad,
+                              uint32_t n_verts, const rt3_material* __restrict__ mats, float4* __restrict__ tri, float4* __restrict__ bound,
+                              float4* __restrict__ mat, uint32_t* __restrict__ kind, uint32_t* __restrict__ error_flag,
+                              u32x4* __restrict__ frag, uint32_t n_frag_rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // matrix-filter fragments: row i of block i/32, for all four operands and both lane halves (padding rows: never candidates)
+    auto write_frag = [&](float cx, float cy, float cz, float kj) {
+        if (i >= n_frag_rows) return;
+        uint32_t fr[4][2][4];
+        bound_frag_row(cx, cy, cz, kj, fr);
+        for (int q = 0; q < 4; q++)
+            for (int hh = 0; hh < 2; hh++)
+                frag[((size_t)(i / 32) * 4 + q) * 64 + hh * 32 + frag_row_of(i % 32)] = u32x4{ fr[q][hh][0], fr[q][hh][1], fr[q][hh][2], fr[q][hh][3] };
+    };
+    if (i >= n_pad && i >= n_frag_rows) return;
+    if (i >= n_faces) { if (i < n_pad) bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
+    const rt3_gface f = faces[i];
+    if (f.v1 >= n_verts || f.v2 >= n_verts || f.v3 >= n_verts) { atomicOr(error_flag, 1u); bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
+    const float4 p1 = verts[f.v1], p2 = verts[f.v2], p3 = verts[f.v3];
+    tri[4 * (size_t)i] = make_float4(f.normal[0], f.normal[1], f.normal[2], dot3(f.normal[0], f.normal[1], f.normal[2], p1.x, p1.y, p1.z));
+    tri[4 * (size_t)i + 1] = make_float4(p1.x, p1.y, p1.z, 0.0f);
+    tri[4 * (size_t)i + 2] = make_float4(p2.x, p2.y, p2.z, 0.0f);
+    tri[4 * (size_t)i + 3] = make_float4(p3.x, p3.y, p3.z, 0.0f);
+    // bounding sphere: centroid + largest vertex distance in double, inflated (0.1 % + 1e-5 * (1 + max |coordinate|)), r^2 rounded up
+    const double cx = ((double)p1.x + p2.x + p3.x) / 3.0, cy = ((double)p1.y + p2.y + p3.y) / 3.0, cz = ((double)p1.z + p2.z + p3.z) / 3.0;
+    double r2 = 0.0, big = 0.0;
+    const float4 ps[3] = { p1, p2, p3 };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double ddx = ps[k].x - cx, ddy = ps[k].y - cy, ddz = ps[k].z - cz;
+        r2 = fmax(r2, ddx * ddx + ddy * ddy + ddz * ddz);
+        big = fmax(big, fmax(fabs((double)ps[k].x), fmax(fabs((double)ps[k].y), fabs((double)ps[k].z))));
+    }
+    const double r = sqrt(r2) * 1.001 + 1e-5 * (1.0 + big);
+    float r2f = (float)(r * r);
+    if ((double)r2f < r * r) r2f = __uint_as_float(__float_as_uint(r2f) + 1u);
+    if (!(r2f >= 0.0f)) r2f = __builtin_inff();                    // NaN / inf vertices: always a candidate, the exact test decides
+    bound[i] = make_float4((float)cx, (float)cy, (float)cz, r2f);
+    {
+        const float fx = (float)cx, fy = (float)cy, fz = (float)cz;
+        const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
+        write_frag(fx, fy, fz, r2f < __builtin_inff() ? filter_kj(c2, (double)r2f) : kAlwaysCandidate);   // r^2 = inf: the exact test decides
+    }
+    if (mats) {
+        const rt3_material m = mats[i];
+        if (m.kind == RT3_MAT_DIELECTRIC) {                         // same packing as pack_material() on the host
+            const float ri_f = 1.0f / m.param, ri_b = m.param;
+            float r0f = (1.0f - ri_f) / (1.0f + ri_f), r0b = (1.0f - ri_b) / (1.0f + ri_b);
+            mat[i] = make_float4(ri_f, r0f * r0f, r0b * r0b, m.param);
+        } else mat[i] = make_float4(m.rgb[0], m.rgb[1], m.rgb[2], m.param);
+        kind[i] = m.kind;
+    }
+    else { mat[i] = make_float4(f.color[0], f.color[1], f.color[2], 0.0f); kind[i] = RT3_MAT_FLAT; }
+}
+
+}  // namespace

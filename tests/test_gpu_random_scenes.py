@@ -70,13 +70,13 @@ def test_random_scene(renderer, seed):
 
 
 def filter_stress_case(seed):
-    """Sphere-only scenes of 100-512 spheres placed far from the origin and at very different scales: the matrix-core
+    """Sphere-only scenes of 100-1100 spheres (both sides of the 512-sphere limit of the all-in-LDS kernel) placed far from the origin and at very different scales: the matrix-core
     candidate filter works on the expanded form |C|^2 - 2 C.o + |o|^2, whose cancellation error grows with the square of the
     coordinates; its margin must grow with it, and the exact test must still see every true hit."""
     rng = np.random.RandomState(1000 + seed)
     scale = float(rng.choice([0.01, 1.0, 1.0, 50.0, 2000.0]))
     offset = rng.choice([0.0, 0.0, 300.0, 5000.0, 60000.0]) * rng.uniform(-1, 1, 3) * scale
-    n = int(rng.choice([100, 257, 400, 484, 512]))
+    n = int(rng.choice([100, 257, 400, 484, 512, 513, 1100]))
     cr = np.zeros((n, 4), np.float64)
     cr[:, :3] = rng.uniform(-6, 6, (n, 3)) * np.float64([1.0, 0.4, 1.0]) + np.float64([0, 0, -9])
     cr[:, 3] = rng.uniform(0.05, 0.9, n) * rng.choice([1.0, 1.0, 0.05], n)
@@ -96,7 +96,7 @@ def filter_stress_case(seed):
                 params=dict(width=w, height=h, spp=4, max_depth=16, seed=seed + 1, flags=1, t_min=float(0.001 * scale)))
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(24))
 def test_matrix_filter_is_conservative_far_from_the_origin(renderer, seed):
     case = filter_stress_case(seed)
     want, casts = oracle_render(case, threads=16)
