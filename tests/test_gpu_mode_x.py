@@ -75,6 +75,27 @@ def test_config2_full_size_rows_against_the_oracle_and_invariances(rt3, renderer
     assert_same(rt3.deinterleave(tiles, plist, H, W), whole, "config 2 sharded")
 
 
+def test_config2_full_frame_equals_the_oracle_frame(rt3, renderer):
+    """The WHOLE headline frame (BASELINE.json configs[1]: 1920x1080, 512 spp, depth 50 — 1.06e9 samples, 2.9e9 ray casts)
+    against the frame the CPU oracle rendered with the same parameters (tests/golden/make_config2_golden.py, minutes of
+    CPU time, done once in the build container): SHA-256 of all pixels, the ray-cast count, and a CRC per row to say where."""
+    import hashlib
+    import json
+    import zlib
+    gold = json.load(open(os.path.join(GOLDEN, "config2_full.json")))
+    cr, mats = rt3.scene_weekend(gold["scene_seed"])
+    W, H = gold["width"], gold["height"]
+    cam = rt3.weekend_camera(W, H)
+    case = dict(spheres=cr, smats=mats, cam=cam.c, params=dict(width=W, height=H, spp=gold["spp"], max_depth=gold["max_depth"],
+                                                              seed=gold["seed"], flags=1, lens_radius=gold["lens_radius"]))
+    img = np.ascontiguousarray(hip_render(renderer, case), dtype="<u4")
+    assert img.shape == (H, W)
+    bad_rows = [y for y in range(H) if zlib.crc32(img[y].tobytes()) != gold["row_crc32"][y]]
+    assert not bad_rows, "%d rows differ from the oracle's frame, first %r" % (len(bad_rows), bad_rows[:8])
+    assert hashlib.sha256(img.tobytes()).hexdigest() == gold["sha256"]
+    assert renderer.stats().ray_casts == gold["ray_casts"]
+
+
 def test_config4_many_spheres_multi_tile(rt3, renderer):
     """BASELINE.json configs[3] shape: 100k Lambertian spheres streamed through LDS in 1024-sphere tiles; 1920x1080 at
     reduced spp, two full-width rows against the oracle + shard invariance of the whole frame."""
