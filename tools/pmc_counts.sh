@@ -1,5 +1,5 @@
 #!/bin/bash
-# VALU / MFMA instruction counts of the bench kernel at spp 128 for a given library: tools/pmc3.sh <tag> [lib path]
+# VALU / MFMA instruction counts of the bench kernel at spp 128 for a given library: tools/pmc_counts.sh <tag> [lib path]
 export TMPDIR=/tmp
 tag=$1
 if [ -n "$2" ]; then export RT3_LIB_PATH=$2; fi
