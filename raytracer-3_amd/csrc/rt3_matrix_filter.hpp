@@ -143,24 +143,29 @@ __device__ __forceinline__ void build_ray_operands(float ox, float oy, float oz,
 // CLEAR <-> sphere 32 blk + b is a candidate); the return value has bit blk set when that word holds any candidate.
 __device__ __forceinline__ uint32_t mfma_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands& R, uint32_t* bm, uint32_t lane) {
     uint32_t nz = 0;                                                // block blk -> bit n_blocks - 1 - blk
+    if (n_blocks == 0) return nz;
+    const u32x4* fr = s_frag + lane;
+    // the operand fragments of a row block are fetched from LDS while the vector ALU decodes the previous block (their
+    // registers are free as soon as that block's last MFMA has issued): the LDS latency is off the critical path
+    u32x4 a0 = fr[0], a1 = fr[64], a2 = fr[128], a3 = fr[192];
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {                 // four row blocks per trip: their LDS offsets are immediates
-        const u32x4* fr0 = s_frag + (size_t)b0 * 256 + lane;
         uint32_t* bm0 = bm + b0 * kMB;
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             if (b0 + u >= n_blocks) break;
-            const u32x4* fr = fr0 + u * 256;
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fr[0]), a1 = __builtin_bit_cast(bf16x8, fr[64]);
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, fr[128]), a3 = __builtin_bit_cast(bf16x8, fr[192]);
             const f32x16 zero = { 0 };
-            f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[0][0]), zero, 0, 0, 0);
-            f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, R.b[1][0]), zero, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[0][0]), d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, R.b[1][0]), d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[0][1]), d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_bit_cast(bf16x8, R.b[1][1]), d1, 0, 0, 0);
-            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[0][2]), d0, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, __builtin_bit_cast(bf16x8, R.b[1][2]), d1, 0, 0, 0);
+            f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, R.b[0][0]), zero, 0, 0, 0);
+            f32x16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, R.b[1][0]), zero, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, R.b[0][0]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, R.b[1][0]), d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a2), __builtin_bit_cast(bf16x8, R.b[0][1]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a2), __builtin_bit_cast(bf16x8, R.b[1][1]), d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3), __builtin_bit_cast(bf16x8, R.b[0][2]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a3), __builtin_bit_cast(bf16x8, R.b[1][2]), d1, 0, 0, 0);
+            if (b0 + u + 1 < n_blocks) {                            // next block's fragments, in flight during the decode below
+                const u32x4* fn = fr + (size_t)(b0 + u + 1) * 256;
+                a0 = fn[0]; a1 = fn[64]; a2 = fn[128]; a3 = fn[192];
+            }
             uint32_t n0 = 0xFFFFFFFFu, n1 = 0xFFFFFFFFu;           // sign bits: register g -> bit 15 - g
 #pragma unroll
             for (int g = 0; g < 16; g++) n0 = __builtin_amdgcn_alignbit(n0, __float_as_uint(d0[g]), 31);
