@@ -475,6 +475,9 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
     ctx->rendered = true;
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
     RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 64, stream));
+#ifdef RT3_PROFILE
+    RT3_HIP(hipMemsetAsync(ctx->d_casts + 6, 0xFF, 8, stream));
+#endif
     if (npix == 0) { RT3_HIP(hipEventRecord(ctx->ev_end, stream)); return 0; }
 
     // batch size: per-sample storage of 16 B per (pixel, sample), capped
@@ -607,6 +610,7 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
         fprintf(stderr, "[rt3 profile] wave iterations %llu, flush iterations/wave-iter %.2f, candidates/ray %.2f, live lanes/wave-iter %.1f, "
                         "fresh paths/wave-iter %.1f\n", counters[4], (double)counters[2] / (double)counters[4],
                 (double)counters[3] / (double)counters[0], (double)counters[0] / (double)counters[4], (double)counters[5] / (double)counters[4]);
+        fprintf(stderr, "[rt3 profile] first wave ended %.1f us before the last one\n", (double)(counters[7] - counters[6]) / 100.0);
 #endif
         out->ray_casts = counters[0];
         out->prim_tests = counters[0] * ((uint64_t)ctx->n_sph + ctx->n_faces);

@@ -319,7 +319,11 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     }
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
 #ifdef RT3_PROFILE
-    if (lane == 0) { atomicAdd(A.cast_counter + 2, prof_flush_iters); atomicAdd(A.cast_counter + 3, prof_cands); atomicAdd(A.cast_counter + 4, iters); atomicAdd(A.cast_counter + 5, prof_refills); }
+    if (lane == 0) {
+        atomicAdd(A.cast_counter + 2, prof_flush_iters); atomicAdd(A.cast_counter + 3, prof_cands); atomicAdd(A.cast_counter + 4, iters); atomicAdd(A.cast_counter + 5, prof_refills);
+        const unsigned long long now = wall_clock64();              // 100 MHz: when the first and the last wave ended, when the queue ran dry
+        atomicMin(A.cast_counter + 6, now); atomicMax(A.cast_counter + 7, now);
+    }
 #endif
 }
 
