@@ -86,10 +86,11 @@ struct RayOperands { u32x4 b[2][3]; };
 // instruction that consumes the result straight after the conversion can read a stale register — about one ray in 10^6 lost a
 // candidate, differently in every run, until wait states were added; hipcc's hazard recognizer inserts none for this opcode
 // (it does for v_permlane32_swap).  The conversion is therefore issued through inline asm with its own `s_nop 3`, which also
-// covers the two wait states a following v_permlane32_swap needs.  tests/test_gpu_repeatability.py guards the property.
+// covers the two wait states a following v_permlane32_swap needs; the leading `s_nop 1` is there because the hazard recognizer
+// cannot see into the asm either and so would not separate it from a producer that needs wait states.  tests/test_gpu_repeatability.py guards the property.
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
     uint32_t r;
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 3" : "=v"(r) : "v"(lo), "v"(hi));
+    asm volatile("s_nop 1\n\tv_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 3" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
 // v_permlane32_swap(x, y): x's upper half-wave <-> y's lower half-wave; set0 = new x, set1 = new y
