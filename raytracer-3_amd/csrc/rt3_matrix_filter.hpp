@@ -298,9 +298,12 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             const float disc = fma_(h, h, -c);
             if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return;
             const float sq = __builtin_sqrtf(disc);
-            float t = h - sq;
-            if (!(t > A.t_min)) t = h + sq;
-            if (t > A.t_min && (t < tbest || (t == tbest && j < ibest))) { tbest = t; ibest = j; kind = 2; }
+            const float t_near = h - sq;
+            const float t = t_near > A.t_min ? t_near : h + sq;
+            // the candidates of a ray come in ascending sphere index (mfma_flush), so "the lower index wins ties" is strict <
+            const bool better = (t > A.t_min) & (t < tbest);
+            tbest = better ? t : tbest;
+            ibest = better ? j : ibest;
         };
         const uint32_t nz = mfma_scan_tile(s_frag, n_blocks, R, s_bm + tid, lane);
 #ifdef RT3_PROFILE
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
         }
 #endif
         mfma_flush(nz, n_blocks, s_bm + tid, eval);
+        kind = tbest < __builtin_inff() ? 2u : 0u;
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
     }
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
