@@ -176,8 +176,8 @@ def main():
         flop = st.prim_tests * FLOP_PER_SPHERE_TEST
         k_ms = trace_ms / max(1, launches)
         achieved = flop / max(1, launches) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        # algorithmic HBM bytes of the same launch: one 16-B radiance record per sample + the scene once per block
-        hbm_bytes = st.samples * 16.0 / max(1, launches)
+        # algorithmic HBM bytes of the same launch: one 12-B radiance record per sample + the scene once per block
+        hbm_bytes = st.samples * 12.0 / max(1, launches)
         # HBM traffic of one k_trace launch from the committed PMC passes of this same command (FETCH_SIZE is doubled as
         # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is; both are in KiB); null if no profile is present
         traffic = None
@@ -217,7 +217,7 @@ def main():
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5) if k_ms > 0 else 0.0,
                              "traffic": traffic,
-                             "note": "algorithmic bytes = 16 B radiance record per sample; the 7.7 KB scene streams through the scalar "
+                             "note": "algorithmic bytes = 12 B radiance record per sample; the 7.7 KB scene streams through the scalar "
                                      "cache; traffic = PMC bytes per launch (profiles/), source of truth for re-reads"},
         }
         try:                                                     # vector-ALU issue utilisation of the same kernel, from the committed PMC pass

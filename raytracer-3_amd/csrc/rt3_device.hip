@@ -58,7 +58,7 @@ struct rt3_ctx {
     float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
     // work buffers
-    float4* d_rad = nullptr; size_t rad_entries = 0;
+    Rgb* d_rad = nullptr; size_t rad_entries = 0;
     float4* d_accum = nullptr; size_t accum_entries = 0;
     uint32_t* d_out = nullptr; size_t out_entries = 0;
     uint32_t* d_work = nullptr;                                     // [0] work counter
@@ -480,8 +480,8 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
 #endif
     if (npix == 0) { RT3_HIP(hipEventRecord(ctx->ev_end, stream)); return 0; }
 
-    // batch size: per-sample storage of 16 B per (pixel, sample), capped
-    uint64_t per_spp = (uint64_t)npix * sizeof(float4);
+    // batch size: per-sample storage of 12 B per (pixel, sample), capped
+    uint64_t per_spp = (uint64_t)npix * sizeof(Rgb);
     uint32_t batch = (uint32_t)std::min<uint64_t>(p->spp, std::max<uint64_t>(1, ctx->rad_cap_bytes / per_spp));
     batch = (uint32_t)std::min<uint64_t>(batch, 0x7FFF0000ull / npix);
     if (batch == 0) return fail(ctx, RT3_E_ARG, "frame too large for one sample batch");

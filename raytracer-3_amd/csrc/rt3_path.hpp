@@ -168,7 +168,7 @@ __device__ __forceinline__ void shade_lane(const TraceArgs& A, Path& P, bool& al
             }
         }
         if (done) {
-            A.rad[P.slot] = make_float4(P.lr, P.lg, P.lb, 0.0f);
+            A.rad[P.slot] = Rgb{ P.lr, P.lg, P.lb };
             alive = false;
         }
     }

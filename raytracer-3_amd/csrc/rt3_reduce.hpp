@@ -5,14 +5,14 @@
 namespace {
 
 // reduce pass (what reduce_v1.glsl:66-76 was meant to be): samples are summed per pixel in sample order.
-__global__ __launch_bounds__(kBlock) void k_accumulate(const float4* __restrict__ rad, float4* __restrict__ accum,
+__global__ __launch_bounds__(kBlock) void k_accumulate(const Rgb* __restrict__ rad, float4* __restrict__ accum,
                                                       uint32_t npix, uint32_t ns, int first) {
     const uint32_t pix = blockIdx.x * kBlock + threadIdx.x;
     if (pix >= npix) return;
     float4 a = first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : accum[pix];
     for (uint32_t s = 0; s < ns; s++) {
-        const float4 r = rad[(size_t)s * npix + pix];
-        a.x = a.x + r.x; a.y = a.y + r.y; a.z = a.z + r.z;
+        const Rgb r = rad[(size_t)s * npix + pix];
+        a.x = a.x + r.r; a.y = a.y + r.g; a.z = a.z + r.b;
     }
     accum[pix] = a;
 }
