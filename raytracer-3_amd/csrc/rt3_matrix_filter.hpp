@@ -87,7 +87,8 @@ struct RayOperands { u32x4 b[2][3]; };
 // candidate, differently in every run, until wait states were added; hipcc's hazard recognizer inserts none for this opcode
 // (it does for v_permlane32_swap).  The conversion is therefore issued through inline asm with its own `s_nop 3`, which also
 // covers the two wait states a following v_permlane32_swap needs; the leading `s_nop 1` is there because the hazard recognizer
-// cannot see into the asm either and so would not separate it from a producer that needs wait states.  tests/test_gpu_repeatability.py guards the property.
+// cannot see into the asm either and so would not separate it from a producer that needs wait states.
+// tests/test_gpu_repeatability.py guards the property.
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
     uint32_t r;
     asm volatile("s_nop 1\n\tv_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 3" : "=v"(r) : "v"(lo), "v"(hi));
