@@ -87,25 +87,43 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
     tri[4 * (size_t)i + 1] = make_float4(p1.x, p1.y, p1.z, 0.0f);
     tri[4 * (size_t)i + 2] = make_float4(p2.x, p2.y, p2.z, 0.0f);
     tri[4 * (size_t)i + 3] = make_float4(p3.x, p3.y, p3.z, 0.0f);
-    // bounding sphere: centroid + largest vertex distance in double, inflated (0.1 % + 1e-5 * (1 + max |coordinate|)), r^2 rounded up
+    // Bounding sphere of the region in which the REFERENCE'S test can report a hit (it must never be smaller: the exact test runs only
+    // on the faces whose bound the ray's line meets).  That region is the triangle p1, p2', p3' in the plane through p1 normal to the
+    // STORED normal, p' = p shifted along that normal (the three edge functions only see the projection along it) — the triangle
+    // itself when the normal is perpendicular to it, which nothing in the interface guarantees.  Centroid + largest distance to the
+    // vertices and their projections, in double, inflated by 0.1 % + 1e-5 (1 + max |coordinate|), r^2 rounded up.
+    // Faces whose edge functions vanish identically have NO bounded hit region — two coincident vertices (the zero edge's function is
+    // -0 >= 0 for every point: three coincident vertices make the test an infinite plane, which is what tiny faces far from the origin
+    // collapse to in f32) or three collinear ones — and non-finite input cannot be bounded either: they are always candidates and the
+    // exact test alone decides, as in the reference (found by tools/fuzz_filter.py).
     const double cx = ((double)p1.x + p2.x + p3.x) / 3.0, cy = ((double)p1.y + p2.y + p3.y) / 3.0, cz = ((double)p1.z + p2.z + p3.z) / 3.0;
     double r2 = 0.0, big = 0.0;
     const float4 ps[3] = { p1, p2, p3 };
+    const double nx = f.normal[0], ny = f.normal[1], nz = f.normal[2], nn = nx * nx + ny * ny + nz * nz;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const double ddx = ps[k].x - cx, ddy = ps[k].y - cy, ddz = ps[k].z - cz;
         r2 = fmax(r2, ddx * ddx + ddy * ddy + ddz * ddz);
         big = fmax(big, fmax(fabs((double)ps[k].x), fmax(fabs((double)ps[k].y), fabs((double)ps[k].z))));
+        if (k > 0 && nn > 0.0) {                                    // the vertex as the edge functions see it
+            const double s = (((double)ps[k].x - p1.x) * nx + ((double)ps[k].y - p1.y) * ny + ((double)ps[k].z - p1.z) * nz) / nn;
+            const double qx = ps[k].x - s * nx - cx, qy = ps[k].y - s * ny - cy, qz = ps[k].z - s * nz - cz;
+            r2 = fmax(r2, qx * qx + qy * qy + qz * qz);
+        }
     }
+    const double e1x = (double)p2.x - p1.x, e1y = (double)p2.y - p1.y, e1z = (double)p2.z - p1.z;
+    const double e2x = (double)p3.x - p1.x, e2y = (double)p3.y - p1.y, e2z = (double)p3.z - p1.z;
+    const bool degenerate = (e1y * e2z - e2y * e1z == 0.0) && (e1z * e2x - e2z * e1x == 0.0) && (e1x * e2y - e2x * e1y == 0.0);   // incl. coincident vertices
     const double r = sqrt(r2) * 1.001 + 1e-5 * (1.0 + big);
     float r2f = (float)(r * r);
     if ((double)r2f < r * r) r2f = __uint_as_float(__float_as_uint(r2f) + 1u);
-    if (!(r2f >= 0.0f)) r2f = __builtin_inff();                    // NaN / inf vertices: always a candidate, the exact test decides
+    const bool always = degenerate || !(r2f < __builtin_inff());    // (NaN compares false)
+    if (always) r2f = 3e38f;                                        // finite: the VALU scan's h^2 - c + 1e-5 c must stay a number
     bound[i] = make_float4((float)cx, (float)cy, (float)cz, r2f);
     {
         const float fx = (float)cx, fy = (float)cy, fz = (float)cz;
         const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
-        write_frag(fx, fy, fz, r2f < __builtin_inff() ? filter_kj(c2, (double)r2f) : kAlwaysCandidate);   // r^2 = inf: the exact test decides
+        write_frag(fx, fy, fz, always ? kAlwaysCandidate : filter_kj(c2, (double)r2f));
     }
     if (mats) {
         const rt3_material m = mats[i];

@@ -132,3 +132,47 @@ def test_bad_arguments_fail_loudly(rt3, renderer):
         renderer.set_mesh(bad.view(rt3.GFACE), verts)
     with pytest.raises(rt3.Fatal):
         renderer.render(rt3.main_camera(1, 1))
+
+
+def _odd_faces(rt3):
+    """Hand-made GFace records the pre-render never produces but the interface accepts: a face whose three vertices coincide
+    (with a VALID stored normal the reference's edge tests are -0 >= 0 everywhere: the face is an infinite plane), a face with
+    two coincident vertices, three collinear vertices, and a normal that is not perpendicular to its triangle (the reference
+    tests the projection along the stored normal).  Plus one ordinary triangle behind them."""
+    # (vertex order: the reference's faces have n = normalize(cross(p3 - p1, p2 - p1)), Sphere.cpp:153; a face wound the other
+    #  way is never hit)
+    tris = [((-2.0, -1.5, -3.0), (0.0, 1.5, -3.0), (2.0, -1.5, -3.0), (0.0, 0.0, 1.0), (0.1, 0.2, 0.9)),      # ordinary, in front
+            ((0.3, 0.2, -4.0), (0.3, 0.2, -4.0), (0.3, 0.2, -4.0), (0.0, 0.6, 0.8), (0.9, 0.1, 0.1)),         # a point with a normal
+            ((-1.0, 0.5, -2.0), (-1.0, 0.5, -2.0), (-0.5, 1.0, -2.0), (0.0, 0.0, 1.0), (0.1, 0.9, 0.1)),      # two coincident vertices
+            ((-1.5, -1.0, -2.0), (0.0, -1.0, -2.0), (1.5, -1.0, -2.0), (0.0, 0.0, 1.0), (0.9, 0.9, 0.1)),     # collinear
+            ((1.2, -0.2, -2.5), (1.7, 0.8, -2.5), (2.2, -0.2, -2.5), (0.6, 0.0, 0.8), (0.9, 0.1, 0.9))]       # skewed normal
+    n = len(tris)
+    faces = np.zeros(n, rt3.GFACE)
+    verts = np.zeros((3 * n, 4), np.float32)
+    for i, (a, b, c, nrm, col) in enumerate(tris):
+        verts[3 * i:3 * i + 3, :3] = (a, b, c)
+        faces[i]["v1"], faces[i]["v2"], faces[i]["v3"] = 3 * i, 3 * i + 1, 3 * i + 2
+        faces[i]["normal"] = nrm
+        faces[i]["color"] = col
+    return faces, verts
+
+
+def test_faces_without_a_bounded_hit_region_behave_as_in_the_reference(rt3, renderer, oracle):
+    """The bounding-sphere filters must never hide a face from the reference's literal test (found by tools/fuzz_filter.py:
+    tiny faces far from the origin collapse to a point in f32 and then 'cover' the whole frame)."""
+    faces, verts = _odd_faces(rt3)
+    w, h = 320, 180
+    ref = oracle.render_mode_r(faces.view(oracle.GFACE), verts, oracle.camera_update(w, h), w, h)
+    assert len(np.unique(ref)) > 3                        # several of the odd faces are visible
+    got = hip_mode_r(rt3, renderer, faces, verts, w, h)
+    assert np.array_equal(got, ref), "k_mode_r_mfma"
+    os.environ["RT3_NO_MFMA"] = "1"
+    try:
+        assert np.array_equal(hip_mode_r(rt3, renderer, faces, verts, w, h), ref), "k_mode_r_fast"
+    finally:
+        del os.environ["RT3_NO_MFMA"]
+    renderer.force_plain_mode_r(True)
+    try:
+        assert np.array_equal(hip_mode_r(rt3, renderer, faces, verts, w, h), ref), "k_mode_r"
+    finally:
+        renderer.force_plain_mode_r(False)

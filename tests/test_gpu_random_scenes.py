@@ -2,6 +2,8 @@
 quad, random look-at cameras, lens, strata, tiles) rendered by the HIP path and by the oracle must be bit-identical.  Seeds are
 fixed; the point is to reach rare branches (total internal reflection chains, absorbed metal rays, near-zero Lambert sums,
 queue overflow, ragged tails of the 4- and 32-sphere scan blocks, faces whose bounding spheres overlap many rays)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -105,3 +107,56 @@ def test_matrix_filter_is_conservative_far_from_the_origin(renderer, seed):
     assert not bad.any(), "seed %d: %d of %d pixels differ" % (seed, bad.sum(), bad.size)
     st = renderer.stats()
     assert st.ray_casts == casts and st.mfma_instructions > 0          # the matrix filter really ran
+
+
+def _both_kernels_against_the_oracle(renderer, case, what):
+    want, casts = oracle_render(case, threads=16)
+    got = hip_render(renderer, case)
+    assert not (got != want).any(), "%s, matrix filter: %d pixels differ" % (what, (got != want).sum())
+    assert renderer.stats().ray_casts == casts
+    os.environ["RT3_NO_MFMA"] = "1"
+    try:
+        got = hip_render(renderer, case, upload=False)
+    finally:
+        del os.environ["RT3_NO_MFMA"]
+    assert not (got != want).any(), "%s, VALU scan: %d pixels differ" % (what, (got != want).sum())
+
+
+@pytest.mark.parametrize("seed", [2067, 2607, 3167, 2875, 2251])
+def test_faces_far_from_the_origin_collapse_to_points_and_still_match(renderer, seed):
+    """Scenes tools/fuzz_filter.py found: triangle soups 10^4 scene sizes away from the origin, where the smallest faces collapse
+    to a point (or a line) in f32 — the reference's edge tests then accept the whole plane — and every bounding-sphere filter
+    that trusted the geometry lost those hits.  Both GPU kernels against the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_filter", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_filter.py"))
+    F = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(F)
+    cr, mats, cam, p, info = F.scene(seed)
+    spread = float(np.abs(cr[:, :3] - np.float32(info["offset"])).mean() / max(info["scale"], 1e-30))
+    faces, verts, fm = F.mesh(seed, info["scale"], np.float64(info["offset"]), max(spread, 1.0))
+    case = dict(faces=faces, verts=verts, fmats=fm, cam=cam.c,
+                params=dict(width=p.width, height=p.height, spp=p.spp, max_depth=p.max_depth, seed=p.seed, flags=p.flags,
+                            lens_radius=p.lens_radius, t_min=p.t_min))
+    if seed % 4 != 3:
+        case.update(spheres=cr, smats=mats)
+    _both_kernels_against_the_oracle(renderer, case, "fuzz seed %d" % seed)
+
+
+def test_mode_x_faces_without_a_bounded_hit_region(renderer):
+    """The hand-made odd faces of test_gpu_mode_r.py (coincident vertices with a valid normal, collinear vertices, a normal that
+    is not perpendicular to its triangle) with materials, next to spheres, in Mode X."""
+    from test_gpu_mode_r import _odd_faces
+    faces, verts = _odd_faces(rt3)
+    fm = np.zeros(len(faces), rt3.MATERIAL)
+    fm["kind"] = [1, 1, 2, 0, 3]
+    fm["rgb"] = faces["color"]
+    fm["param"] = [0.0, 0.0, 0.2, 0.0, 1.5]
+    cr = np.float32([[0.0, -0.3, -2.0, 0.4], [1.2, 0.6, -3.0, 0.5]])
+    sm = np.zeros(2, rt3.MATERIAL)
+    sm["kind"] = [3, 2]
+    sm["rgb"] = [[1, 1, 1], [0.8, 0.7, 0.3]]
+    sm["param"] = [1.5, 0.1]
+    cam = rt3.main_camera(160, 90)
+    case = dict(faces=faces, verts=verts, fmats=fm, spheres=cr, smats=sm, cam=cam.c,
+                params=dict(width=160, height=90, spp=4, max_depth=12, seed=5, flags=1))
+    _both_kernels_against_the_oracle(renderer, case, "odd faces")
