@@ -52,6 +52,9 @@ def mesh(seed, scale, offset, spread):
     nrm = np.cross(v[:, 2] - v[:, 0], v[:, 1] - v[:, 0]).astype(np.float32)
     ln = np.sqrt((nrm * nrm).sum(1, dtype=np.float32))
     faces["normal"] = np.where(ln[:, None] > 0, nrm / np.maximum(ln, np.float32(1e-30))[:, None], np.float32([0, 0, 1]))
+    if rng.rand() < 0.3:                                             # stored normals that are neither unit nor perpendicular
+        odd = rng.rand(n) < 0.3
+        faces["normal"][odd] = (faces["normal"][odd] + rng.normal(0, 0.7, (odd.sum(), 3))) * rng.uniform(0.2, 3.0, (odd.sum(), 1))
     faces["color"] = rng.uniform(0.1, 1.0, (n, 3))
     fm = np.zeros(n, rt3.MATERIAL)
     fm["kind"] = rng.randint(0, 4, n)
@@ -77,6 +80,20 @@ def main():
         else:
             r.set_mesh(*empty)
         r.set_spheres(cr, mats)
+        if seed % 2 and seed % 3 == 0:                               # Mode R as well: matrix filter against the plain brute force
+            mcam = rt3.main_camera(160, 90)
+            shift = np.float32(info["offset"]) + np.float32([0, 0, 3 * info["scale"] * max(spread, 1.0)])
+            vr = verts.copy(); vr[:, :3] -= shift                    # the Mode-R camera sits at the origin looking down -z
+            r.set_mesh(faces, vr, fm)
+            r.configure(spp=None)
+            r.render(mcam); a = mcam.get_frame().d().copy()
+            r.force_plain_mode_r(True)
+            r.render(mcam); b = mcam.get_frame().d().copy()
+            r.force_plain_mode_r(False)
+            if (a != b).any():
+                bad_total += 1
+                print("seed %d: MODE R %d pixels differ  %r" % (seed, int((a != b).sum()), info), flush=True)
+            r.set_mesh(faces, verts, fm)
         os.environ["RT3_NO_MFMA"] = "1"
         ref = r.render_path(cam.c, p).copy()
         del os.environ["RT3_NO_MFMA"]
