@@ -38,3 +38,16 @@ def test_tiled_scene_matrix_filter_equals_valu_scan_every_time(rt3, renderer):
     renderer.set_spheres(cr, mats)
     p = rt3.make_params(W, H, spp=8, max_depth=20, seed=5, flags=1)
     _render_both(renderer, lambda: renderer.render_path(cam.c, p), runs=3)
+
+
+def test_differential_fuzz_of_the_two_candidate_searches(renderer):
+    """A slice of tools/fuzz_filter.py (the campaign behind DESIGN.md §5.1: 54 000 scenes): random sphere scenes and triangle soups —
+    far from the origin, five decades of sizes, degenerate faces, skewed stored normals — rendered by the matrix-filter kernels
+    and by the VALU-scan kernels (Mode X) and by the matrix filter and the plain brute force (Mode R)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_filter", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_filter.py"))
+    F = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(F)
+    messages = []
+    bad = F.run(240, 500000, r=renderer, log=messages.append)
+    assert bad == 0, "\n".join(m for m in messages if m.startswith("seed"))
