@@ -1,0 +1,53 @@
+"""bench.py's output contract: one JSON line with the fields the driver reads, plus the `roofline` and `cpu_baseline` objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = run_bench("--steps", "1", "--warmup", "0", "--cpu-seconds", "0")
+    assert p.returncode != 0
+    assert "needs a GPU" in (p.stdout + p.stderr)              # no CPU fallback: the product path fails loudly
+
+
+def test_bench_refuses_a_world_size_that_does_not_match():
+    p = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stdout + p.stderr)
+
+
+@pytest.mark.gpu
+def test_bench_line_has_every_field_of_the_contract():
+    p = run_bench("--spp", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                         # ONE JSON line
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Msamples/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 1920 * 1080 * 8 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
