@@ -71,6 +71,15 @@ typedef struct rt3_material {
 
 #define RT3_FLAG_GAMMA2            1u   /* sqrt() each channel before packing (book gamma 2)           */
 #define RT3_FLAG_BLACK_BACKGROUND  2u   /* a miss contributes nothing (default: the reference's sky)    */
+/* The primary ray (ray cast 0) is traced exactly as SequentialRenderer.cpp:289-297 does it: the direction is left
+ * UNNORMALISED (:293), faces are tested with the reference's literal formula t = (n.o + n.p1) / (n.d) (:70, sic) and
+ * a miss shades sky(d) of that unnormalised d (:105-107).  With spp 1, max_depth 1, flat faces, t_min 0 and no
+ * gamma, Mode X then IS Mode R, byte for byte (consequence 1(i)); later ray casts are the
+ * normal Mode-X ones.  Triangle-only scenes. */
+#define RT3_FLAG_REFERENCE_PRIMARY 4u
+/* Keep a per-pixel, per-channel sum of squared sample radiances beside the sums (variance estimates; the
+ * "sample storage" half of reduce_v1.glsl's intent).  Read both back with rt3_accum_download(). */
+#define RT3_FLAG_VARIANCE          8u
 
 /* Parameters of a Mode-X render.  tile_*: interleaved row-block sharding of the framebuffer
  * (design intent: BlockInfo{x,y,w,h} of raytracer_v4.glsl:70-79).  Row-block b (tile_rows rows) belongs
@@ -98,6 +107,8 @@ typedef struct rt3_stats {
     uint32_t n_spheres, n_faces;
     uint32_t _pad;
     uint64_t mfma_instructions;  /* v_mfma_f32_32x32x16_bf16 wave-instructions issued by the candidate filter (0: VALU scan) */
+    uint64_t exact_tests;        /* (ray, primitive) pairs that survived the filter and went through the exact test
+                                    (counted by the tiled matrix-filter kernels; 0 elsewhere)                            */
 } rt3_stats;
 
 typedef struct rt3_ctx rt3_ctx;
@@ -157,6 +168,45 @@ int rt3_render_path(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* param
 /* Mode X, asynchronous on `stream`, device output. */
 int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* params,
                            void* d_out_pixels, void* stream);
+
+/* Progressive / resumable form (design intent reduce_v1.glsl:28-76 + the SampleStorage of
+ * raytracer_v4.glsl:107-111): renders samples [sample_begin, sample_begin + sample_count) of the params->spp samples
+ * per pixel and adds them, in sample order, to the per-pixel accumulators the context keeps between calls; the output
+ * is the frame resolved over the samples accumulated so far (sum / (sample_begin + sample_count)).  sample_begin == 0
+ * starts a new accumulation; otherwise it must equal the number of samples already accumulated for the SAME camera and
+ * params (RT3_E_STATE if not).  Any partition of [0, spp) into consecutive calls gives the frame of one
+ * rt3_render_path*() call, bit for bit.  rt3_render_path_device(p) == rt3_render_path_range_device(p, 0, p->spp). */
+int rt3_render_path_range(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* params,
+                          uint32_t sample_begin, uint32_t sample_count, uint32_t* out_pixels);
+int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* params,
+                                 uint32_t sample_begin, uint32_t sample_count, void* d_out_pixels, void* stream);
+/* Checkpoint / resume of that accumulation.  Download: sum (and, when the accumulation runs with
+ * RT3_FLAG_VARIANCE and sum_sq != NULL, the sums of squares) as 4 floats per owned pixel (r, g, b, 0), compact tile
+ * rows as rt3_render_path writes them; *samples_done = samples accumulated.  Upload: restores such a state for
+ * (cam, params) — possibly into another context or process — so that the next rt3_render_path_range() call continues
+ * at sample_begin == samples_done.  sum_sq may be NULL when params->flags lacks RT3_FLAG_VARIANCE. */
+int rt3_accum_download(rt3_ctx* ctx, float* sum_rgba, float* sum_sq_rgba, uint32_t* samples_done);
+int rt3_accum_upload(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* params,
+                     const float* sum_rgba, const float* sum_sq_rgba, uint32_t samples_done);
+
+/* Multi-GPU gather of final pixels without the host ("hipMemcpyPeerAsync into rank 0's buffer at
+ * the right offsets, no de-interleave needed"; tiling intent BlockInfo, raytracer_v4.glsl:70-79).  d_tile holds the
+ * compact rows of the shard described by shard_params (as rt3_render_path_device wrote them) on the device of
+ * `shard`; they are copied to their interleaved positions inside the full frame d_frame (width*height words) on the
+ * device of `root` — one strided 2-D device-to-device copy (peer-to-peer over xGMI when the two contexts sit on
+ * different GPUs; peer access is enabled on first use) plus one 1-D copy when the last row block is ragged.  The
+ * copies are issued on `stream`, which must be a stream of the SHARD's device (NULL = the shard context's own stream),
+ * so that they run behind the shard's resolve kernel.  root == shard is allowed (single GPU). */
+int rt3_gather_rows(rt3_ctx* root, void* d_frame, rt3_ctx* shard, const void* d_tile,
+                    const rt3_params* shard_params, void* stream);
+/* The context's own stream (a hipStream_t) and a wait for it — what a multi-device host needs around rt3_gather_rows. */
+void* rt3_stream(rt3_ctx* ctx);
+int   rt3_synchronize(rt3_ctx* ctx);
+/* Device frame buffer helpers for hosts that have no other HIP binding: allocate / free n_words uint32 on the
+ * context's device, and copy such a buffer to the host (synchronous, after everything queued on the ctx stream). */
+void* rt3_device_alloc_words(rt3_ctx* ctx, uint64_t n_words);
+void  rt3_device_free(rt3_ctx* ctx, void* d_ptr);
+int   rt3_device_read_words(rt3_ctx* ctx, const void* d_ptr, uint64_t n_words, uint32_t* out);
 
 /* Rows of the frame owned by shard tile_index (see rt3_params), and the frame row of local row i. */
 uint32_t rt3_rows_owned(const rt3_params* params);
@@ -219,6 +269,10 @@ float    rt3_random_float(uint32_t m);
 /* Debug switch used by the parity tests only: non-zero makes rt3_render* always take the plain brute-force Mode-R kernel
  * instead of the bounding-sphere-filtered one (both must give identical pixels). */
 int      rt3_debug_force_plain_mode_r(rt3_ctx* ctx, int on);
+/* Debug switch used by the parity tests and the fuzzers only: non-zero makes rt3_render_path* take k_trace_brute, the
+ * UNFILTERED Mode-X kernel (every ray against every primitive in index order, no bounding spheres, no matrix cores) —
+ * the on-GPU arbiter for the candidate filters.  Same effect: environment variable RT3_BRUTE=1. */
+int      rt3_debug_force_brute(rt3_ctx* ctx, int on);
 int      rt3_debug_arith(rt3_ctx* ctx, const float* a, const float* b, uint32_t n, float* div, float* sq, float* fm,
                          float* cs, float* sn, float* sk3, uint32_t* pk);
 

@@ -350,7 +350,9 @@ typedef struct {
 
 /* nearest hit; kind 0 none, 1 triangle, 2 sphere.  Triangles first, then spheres; strict '<' keeps the
  * earlier primitive on equal t (raytracer_v4.glsl:226-246). */
-static int nearest(const scene_t* sc, v3 o, v3 d, float tmin, float* t_out, uint32_t* i_out) {
+/* literal: the reference's own t = (n.o + n.p1) / (n.d), SequentialRenderer.cpp:70 (sic) — ray cast 0 under
+ * RT3_FLAG_REFERENCE_PRIMARY. */
+static int nearest(const scene_t* sc, v3 o, v3 d, float tmin, int literal, float* t_out, uint32_t* i_out) {
     float tbest = INFINITY; uint32_t ibest = 0; int kind = 0;
     for (uint32_t i = 0; i < sc->nf; i++) {                          /* hit_vertex, raytracer_v4.glsl:116-153, with the */
         const rt3_gface* f = &sc->faces[i];                          /* sign of n.o corrected for origin != 0           */
@@ -358,7 +360,7 @@ static int nearest(const scene_t* sc, v3 o, v3 d, float tmin, float* t_out, uint
         float nd = dot3(d, n);
         if (nd == 0) continue;
         v3 p1 = v3p(&sc->verts[4 * f->v1]), p2 = v3p(&sc->verts[4 * f->v2]), p3 = v3p(&sc->verts[4 * f->v3]);
-        float t = (dot3(n, p1) - dot3(n, o)) / nd;
+        float t = literal ? (dot3(n, o) + dot3(n, p1)) / nd : (dot3(n, p1) - dot3(n, o)) / nd;
         if (!(t >= tmin && t < tbest)) continue;
         v3 hit = vadd(o, vscale(t, d));
         v3 a = cross3(vsub(p2, p1), vsub(hit, p1));
@@ -416,14 +418,18 @@ static v3 sample_radiance(const scene_t* sc, const rt3_camera* cam, const rt3_pa
         o = vadd(org, off);
         dir = vsub(dir, off);
     }
+    /* RT3_FLAG_REFERENCE_PRIMARY: ray cast 0 is the reference's — unnormalised direction (SequentialRenderer.cpp:293),
+     * literal plane formula (:70), sky of that direction (:105-107), hit point o + t d with them (:77); the scatter
+     * formulas then get the unit direction.  Otherwise the direction is normalised here. */
+    const int ref = (P->flags & RT3_FLAG_REFERENCE_PRIMARY) != 0;
     float inv = 1.0f / sqrtf(dot3(dir, dir));
-    v3 d = V(dir.x * inv, dir.y * inv, dir.z * inv);
+    v3 d = ref ? dir : V(dir.x * inv, dir.y * inv, dir.z * inv);
 
     v3 L = V(0, 0, 0), thr = V(1, 1, 1);
     for (uint32_t k = 0; k < P->max_depth; k++) {
         float t; uint32_t idx;
         ++*casts;
-        int kind = nearest(sc, o, d, P->t_min, &t, &idx);
+        int kind = nearest(sc, o, d, P->t_min, ref && k == 0, &t, &idx);
         if (!kind) {
             if (!(P->flags & RT3_FLAG_BLACK_BACKGROUND)) { v3 c = sky(d); L = V(fmaf(thr.x, c.x, L.x), fmaf(thr.y, c.y, L.y), fmaf(thr.z, c.z, L.z)); }
             break;
@@ -445,6 +451,7 @@ static v3 sample_radiance(const scene_t* sc, const rt3_camera* cam, const rt3_pa
         v3 rgb = v3p(m.rgb);
         if (m.kind == RT3_MAT_FLAT) { L = V(fmaf(thr.x, rgb.x, L.x), fmaf(thr.y, rgb.y, L.y), fmaf(thr.z, rgb.z, L.z)); break; }
         if (k + 1 == P->max_depth) break;
+        if (ref && k == 0) { float iv = 1.0f / sqrtf(dot3(d, d)); d = V(d.x * iv, d.y * iv, d.z * iv); }
         int front = dotf(d, nout) < 0.0f;
         v3 n = front ? nout : vneg(nout);
         uint32_t ctr = 1 + 8 * (k + 1);
@@ -496,34 +503,62 @@ uint32_t oracle_rows_owned(const rt3_params* P) {
     return n;
 }
 
-/* Renders the rows this shard owns into a compact buffer.  out_sum (optional) receives the per-pixel float
- * sums (3 floats per pixel) before the division by spp.  Returns ray casts. */
-uint64_t oracle_render_path(const rt3_gface* faces, uint32_t nf, const float* verts, const rt3_material* fmats,
-                            const float* spheres, const rt3_material* smats, uint32_t ns,
-                            const rt3_camera* cam, const rt3_params* P, uint32_t* out, float* out_sum, int threads) {
+/* Renders samples [s_begin, s_begin + s_count) of the rows this shard owns (compact buffer) and adds them, in sample
+ * order, to the running per-pixel sums — the progressive accumulation of rt3_render_path_range (design intent:
+ * reduce_v1.glsl:28-76).  sum_io / sumsq_io: 4 floats per pixel (r, g, b, 0), read when s_begin > 0, written back;
+ * both optional (sumsq_io is only touched with RT3_FLAG_VARIANCE: sq = fma(L, L, sq)).  out = the frame resolved over
+ * the s_begin + s_count samples so far.  Returns ray casts (UINT64_MAX: unsupported combination). */
+uint64_t oracle_render_path_range(const rt3_gface* faces, uint32_t nf, const float* verts, const rt3_material* fmats,
+                                  const float* spheres, const rt3_material* smats, uint32_t ns,
+                                  const rt3_camera* cam, const rt3_params* P, uint32_t s_begin, uint32_t s_count,
+                                  uint32_t* out, float* sum_io, float* sumsq_io, int threads) {
+    if ((P->flags & RT3_FLAG_REFERENCE_PRIMARY) && ns != 0) return UINT64_MAX;      /* triangle-only, as the product */
+    if (s_begin != 0 && !sum_io) return UINT64_MAX;
     scene_t sc = { faces, nf, verts, fmats, spheres, smats, ns };
     uint32_t* rows = (uint32_t*)malloc(sizeof(uint32_t) * (P->height ? P->height : 1));
     uint32_t nrows = 0;
     for (uint32_t y = 0; y < P->height; y++) if (row_owned(P, y)) rows[nrows++] = y;
+    const int var = (P->flags & RT3_FLAG_VARIANCE) != 0 && sumsq_io != NULL;
     uint64_t casts = 0;
     #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1) reduction(+:casts)
     for (uint32_t r = 0; r < nrows; r++) {
         uint32_t y = rows[r];
         for (uint32_t x = 0; x < P->width; x++) {
-            v3 sum = V(0, 0, 0);
-            for (uint32_t s = 0; s < P->spp; s++) {                  /* reduce_v1.glsl intent: samples summed in order */
+            size_t li = (size_t)r * P->width + x;
+            v3 sum = V(0, 0, 0), sq = V(0, 0, 0);
+            if (s_begin != 0) {
+                sum = v3p(&sum_io[4 * li]);
+                if (var) sq = v3p(&sumsq_io[4 * li]);
+            }
+            for (uint32_t s = s_begin; s < s_begin + s_count; s++) {  /* reduce_v1.glsl intent: samples summed in order */
                 v3 L = sample_radiance(&sc, cam, P, x, y, s, &casts);
                 sum = vadd(sum, L);
+                if (var) sq = V(fmaf(L.x, L.x, sq.x), fmaf(L.y, L.y, sq.y), fmaf(L.z, L.z, sq.z));
             }
-            size_t li = (size_t)r * P->width + x;
-            if (out_sum) { out_sum[3 * li] = sum.x; out_sum[3 * li + 1] = sum.y; out_sum[3 * li + 2] = sum.z; }
-            float n = (float)P->spp;
+            if (sum_io) { sum_io[4 * li] = sum.x; sum_io[4 * li + 1] = sum.y; sum_io[4 * li + 2] = sum.z; sum_io[4 * li + 3] = 0.0f; }
+            if (var) { sumsq_io[4 * li] = sq.x; sumsq_io[4 * li + 1] = sq.y; sumsq_io[4 * li + 2] = sq.z; sumsq_io[4 * li + 3] = 0.0f; }
+            float n = (float)(s_begin + s_count);
             v3 c = V(sum.x / n, sum.y / n, sum.z / n);
             if (P->flags & RT3_FLAG_GAMMA2) c = V(c.x > 0 ? sqrtf(c.x) : 0.0f, c.y > 0 ? sqrtf(c.y) : 0.0f, c.z > 0 ? sqrtf(c.z) : 0.0f);
             out[li] = pack_pixel(c);
         }
     }
     free(rows);
+    return casts;
+}
+
+/* The whole render: samples [0, spp).  out_sum (optional): the per-pixel sums, 3 floats per pixel. */
+uint64_t oracle_render_path(const rt3_gface* faces, uint32_t nf, const float* verts, const rt3_material* fmats,
+                            const float* spheres, const rt3_material* smats, uint32_t ns,
+                            const rt3_camera* cam, const rt3_params* P, uint32_t* out, float* out_sum, int threads) {
+    float* sum4 = NULL;
+    size_t npix = (size_t)oracle_rows_owned(P) * P->width;
+    if (out_sum) sum4 = (float*)malloc(sizeof(float) * 4 * (npix ? npix : 1));
+    uint64_t casts = oracle_render_path_range(faces, nf, verts, fmats, spheres, smats, ns, cam, P, 0, P->spp, out, sum4, NULL, threads);
+    if (out_sum) {
+        for (size_t i = 0; i < npix; i++) { out_sum[3 * i] = sum4[4 * i]; out_sum[3 * i + 1] = sum4[4 * i + 1]; out_sum[3 * i + 2] = sum4[4 * i + 2]; }
+        free(sum4);
+    }
     return casts;
 }
 
@@ -539,7 +574,7 @@ uint32_t oracle_pack_pixel(float r, float g, float b) { return pack_pixel(V(r, g
 int oracle_nearest(const rt3_gface* faces, uint32_t nf, const float* verts, const float* spheres, uint32_t ns,
                    const float* o, const float* d, float tmin, float* t, uint32_t* idx) {
     scene_t sc = { faces, nf, verts, NULL, spheres, NULL, ns };
-    return nearest(&sc, v3p(o), v3p(d), tmin, t, idx);
+    return nearest(&sc, v3p(o), v3p(d), tmin, 0, t, idx);
 }
 /* Mode-R colour of one ray (ray_color, SequentialRenderer.cpp:47-109). */
 void oracle_ray_color(const rt3_gface* faces, uint32_t nf, const float* verts, const float* o, const float* d, float* rgb) {

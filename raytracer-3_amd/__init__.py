@@ -37,7 +37,7 @@ GFACE = np.dtype([("v1", "<u4"), ("v2", "<u4"), ("v3", "<u4"), ("_p0", "<u4"),
 MATERIAL = np.dtype([("rgb", "<f4", 3), ("param", "<f4"), ("kind", "<u4")])
 
 MAT_FLAT, MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
-FLAG_GAMMA2, FLAG_BLACK_BACKGROUND = 1, 2
+FLAG_GAMMA2, FLAG_BLACK_BACKGROUND, FLAG_REFERENCE_PRIMARY, FLAG_VARIANCE = 1, 2, 4, 8
 
 
 class rt3_camera(C.Structure):
@@ -54,7 +54,8 @@ class rt3_params(C.Structure):
 class rt3_stats(C.Structure):
     _fields_ = [("ray_casts", C.c_uint64), ("prim_tests", C.c_uint64), ("samples", C.c_uint64),
                 ("trace_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint32),
-                ("n_spheres", C.c_uint32), ("n_faces", C.c_uint32), ("_pad", C.c_uint32), ("mfma_instructions", C.c_uint64)]
+                ("n_spheres", C.c_uint32), ("n_faces", C.c_uint32), ("_pad", C.c_uint32), ("mfma_instructions", C.c_uint64),
+                ("exact_tests", C.c_uint64)]
 
 
 class Fatal(RuntimeError):
@@ -71,6 +72,8 @@ EXPORTS = [
     "rt3_scene_three_spheres", "rt3_scene_weekend", "rt3_scene_stress", "rt3_scene_cornell", "rt3_hash_u32",
     "rt3_random_float", "rt3_debug_arith", "rt3_debug_force_plain_mode_r",
     "rt3_mesh_begin", "rt3_mesh_put", "rt3_mesh_sphere", "rt3_mesh_commit", "rt3_mesh_download",
+    "rt3_render_path_range", "rt3_render_path_range_device", "rt3_accum_download", "rt3_accum_upload", "rt3_gather_rows",
+    "rt3_stream", "rt3_synchronize", "rt3_device_alloc_words", "rt3_device_free", "rt3_device_read_words", "rt3_debug_force_brute",
 ]
 
 _lib = None
@@ -116,6 +119,12 @@ def lib():
         "rt3_mesh_begin": (i32, [vp, u32, u32]), "rt3_mesh_put": (i32, [vp, vp, u32, vp, u32, u32, u32]),
         "rt3_mesh_sphere": (i32, [vp, vp, f32, u32, u32, vp, u32, u32]), "rt3_mesh_commit": (i32, [vp, vp]),
         "rt3_mesh_download": (i32, [vp, vp, vp]),
+        "rt3_render_path_range": (i32, [vp, vp, vp, u32, u32, vp]),
+        "rt3_render_path_range_device": (i32, [vp, vp, vp, u32, u32, vp, vp]),
+        "rt3_accum_download": (i32, [vp, vp, vp, vp]), "rt3_accum_upload": (i32, [vp, vp, vp, vp, vp, u32]),
+        "rt3_gather_rows": (i32, [vp, vp, vp, vp, vp, vp]), "rt3_stream": (vp, [vp]), "rt3_synchronize": (i32, [vp]),
+        "rt3_device_alloc_words": (vp, [vp, u64]), "rt3_device_free": (None, [vp, vp]),
+        "rt3_device_read_words": (i32, [vp, vp, u64, vp]), "rt3_debug_force_brute": (i32, [vp, i32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -518,6 +527,41 @@ class HipRenderer(Renderer):
         out = np.zeros((rows, params.width), np.uint32)
         self._check(lib().rt3_render_path(self._ctx, C.byref(camera_c), C.byref(params), _p(out)))
         return out
+
+    def render_path_range(self, camera_c, params, sample_begin, sample_count):
+        """Progressive Mode X (rt3_render_path_range): adds samples [begin, begin + count) to the accumulation this renderer
+        keeps and returns the frame resolved over the samples so far.  begin == 0 starts over."""
+        rows = lib().rt3_rows_owned(C.byref(params))
+        out = np.zeros((rows, params.width), np.uint32)
+        self._check(lib().rt3_render_path_range(self._ctx, C.byref(camera_c), C.byref(params), sample_begin, sample_count, _p(out)))
+        return out
+
+    def render_path_range_device(self, camera_c, params, sample_begin, sample_count, d_out_ptr, stream_ptr=None):
+        self._check(lib().rt3_render_path_range_device(self._ctx, C.byref(camera_c), C.byref(params), sample_begin, sample_count,
+                                                       C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr or 0)))
+
+    def accum_download(self, params, want_sq=False):
+        """Checkpoint of the accumulation: (sum[rows, w, 4], sum_sq or None, samples_done)."""
+        rows = lib().rt3_rows_owned(C.byref(params))
+        acc = np.zeros((rows, params.width, 4), np.float32)
+        sq = np.zeros((rows, params.width, 4), np.float32) if want_sq else None
+        done = C.c_uint32(0)
+        self._check(lib().rt3_accum_download(self._ctx, _p(acc), _p(sq), C.byref(done)))
+        return acc, sq, done.value
+
+    def accum_upload(self, camera_c, params, acc, sq, samples_done):
+        acc = np.ascontiguousarray(acc, np.float32)
+        sq = None if sq is None else np.ascontiguousarray(sq, np.float32)
+        self._check(lib().rt3_accum_upload(self._ctx, C.byref(camera_c), C.byref(params), _p(acc), _p(sq), samples_done))
+
+    def gather_rows(self, d_frame_ptr, shard_renderer, d_tile_ptr, shard_params, stream_ptr=None):
+        """rt3_gather_rows: the shard's compact rows -> their interleaved places in this (root) renderer's device frame."""
+        self._check(lib().rt3_gather_rows(self._ctx, C.c_void_p(d_frame_ptr), shard_renderer._ctx, C.c_void_p(d_tile_ptr),
+                                          C.byref(shard_params), C.c_void_p(stream_ptr or 0)))
+
+    def force_brute(self, on):
+        """Tests / fuzzers: the unfiltered Mode-X kernel (every ray against every primitive)."""
+        self._check(lib().rt3_debug_force_brute(self._ctx, 1 if on else 0))
 
     def render_path_device(self, camera_c, params, d_out_ptr, stream_ptr=None):
         """Asynchronous Mode X into a device buffer (e.g. a torch tensor's data_ptr()) on a HIP stream."""

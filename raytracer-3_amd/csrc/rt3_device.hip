@@ -25,6 +25,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <set>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -60,11 +62,18 @@ struct rt3_ctx {
     // work buffers
     Rgb* d_rad = nullptr; size_t rad_entries = 0;
     float4* d_accum = nullptr; size_t accum_entries = 0;
+    float4* d_accum_sq = nullptr; size_t accum_sq_entries = 0;      // RT3_FLAG_VARIANCE: per-pixel sums of squares
     uint32_t* d_out = nullptr; size_t out_entries = 0;
     uint32_t* d_work = nullptr;                                     // [0] work counter
     unsigned long long* d_casts = nullptr;
     uint64_t rad_cap_bytes = 16ull << 30;
     bool force_plain_mode_r = false;                                // tests: compare the two Mode-R kernels
+    bool force_brute = false;                                       // tests / fuzzers: unfiltered Mode-X kernel
+    // the accumulation a progressive render continues (rt3_render_path_range): what it belongs to and how far it got
+    bool acc_valid = false; rt3_params acc_params{}; rt3_camera acc_cam{}; uint32_t acc_done = 0; uint32_t acc_npix = 0;
+    // launch configuration per (kernel, dynamic LDS): max dynamic LDS attribute set, workgroups per CU
+    std::map<std::pair<const void*, size_t>, int> occupancy;
+    std::set<int> peers_enabled;                                    // devices this context's device may already write to
 
     // stats of the last render
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;              // per dominant-kernel launch
@@ -74,6 +83,7 @@ struct rt3_ctx {
     uint64_t last_samples = 0;
     bool last_was_path = false;
     bool rendered = false;
+    // what the render in flight will report once its last launch has been issued (committed only then)
 };
 
 namespace {
@@ -202,8 +212,26 @@ bool row_owned(const rt3_params* p, uint32_t y) {
     return ((y / p->tile_rows) % p->tile_count) == p->tile_index;
 }
 
+// Workgroups per CU of `kernel` with `lds` bytes of dynamic LDS; the attribute and the query run once per (kernel, lds).
+int blocks_per_cu(rt3_ctx* ctx, const void* kernel, int block, size_t lds, int* out) {
+    const auto key = std::make_pair(kernel, lds);
+    const auto it = ctx->occupancy.find(key);
+    if (it != ctx->occupancy.end()) { *out = it->second; return 0; }
+    if (lds > 48 * 1024) RT3_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int n = 0;
+    RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, lds));
+    ctx->occupancy[key] = n;
+    *out = n;
+    return 0;
+}
+
+bool same_bytes(const void* a, const void* b, size_t n) { return std::memcmp(a, b, n) == 0; }
+
 int check_params(rt3_ctx* ctx, const rt3_params* p) {
     if (!p) return fail(ctx, RT3_E_ARG, "params is NULL");
+    if (!(p->t_min >= 0.0f) || !(p->t_min < __builtin_inff())) return fail(ctx, RT3_E_ARG, "t_min must be finite and >= 0");
+    if (p->flags & ~(RT3_FLAG_GAMMA2 | RT3_FLAG_BLACK_BACKGROUND | RT3_FLAG_REFERENCE_PRIMARY | RT3_FLAG_VARIANCE))
+        return fail(ctx, RT3_E_ARG, "unknown bits in flags");
     if (p->width < 2 || p->height < 2) return fail(ctx, RT3_E_ARG, "width and height must be >= 2");
     if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(ctx, RT3_E_ARG, "frame too large");
     if (p->spp < 1 || p->max_depth < 1) return fail(ctx, RT3_E_ARG, "spp and max_depth must be >= 1");
@@ -256,7 +284,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
-                     ctx->d_rad, ctx->d_accum, ctx->d_out, ctx->d_work, ctx->d_casts };
+                     ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -406,28 +434,68 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
     return 0;
 }
 
+int rt3_debug_force_brute(rt3_ctx* ctx, int on) {
+    if (!ctx) return RT3_E_ARG;
+    ctx->force_brute = on != 0;
+    return 0;
+}
+
+void* rt3_stream(rt3_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rt3_synchronize(rt3_ctx* ctx) {
+    if (!ctx) return RT3_E_ARG;
+    RT3_HIP(hipSetDevice(ctx->device));
+    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void* rt3_device_alloc_words(rt3_ctx* ctx, uint64_t n_words) {
+    if (!ctx || n_words == 0) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&p, n_words * 4) != hipSuccess) { ctx->err = "rt3_device_alloc_words: hipMalloc failed"; return nullptr; }
+    return p;
+}
+void rt3_device_free(rt3_ctx* ctx, void* d_ptr) {
+    if (!ctx || !d_ptr) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipFree(d_ptr);
+}
+int rt3_device_read_words(rt3_ctx* ctx, const void* d_ptr, uint64_t n_words, uint32_t* out) {
+    if (!ctx) return RT3_E_ARG;
+    if (!d_ptr || !out) return fail(ctx, RT3_E_ARG, "rt3_device_read_words: NULL buffer");
+    RT3_HIP(hipSetDevice(ctx->device));
+    RT3_HIP(hipMemcpyAsync(out, d_ptr, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint32_t height, void* d_out, void* stream_) {
     if (!ctx) return RT3_E_ARG;
     if (!cam || !d_out) return fail(ctx, RT3_E_ARG, "cam / d_out_pixels is NULL");
     if (width < 2 || height < 2 || (uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RT3_E_ARG, "bad frame size");
     RT3_HIP(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
+    ctx->rendered = false;                                          // stats are valid again once every launch below has been issued
     ctx->ev_used = 0;
     hipEvent_t a, b;
     int rc = take_event_pair(ctx, &a, &b);
     if (rc) return rc;
     const uint32_t npix = width * height;
-    RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
-    RT3_HIP(hipEventRecord(a, stream));
-    // k_mode_r_fast needs n.o == 0 exactly (camera at the origin, as Camera::update always builds it) and finite rays;
+    // k_mode_r_mfma / k_mode_r_fast need n.o == 0 exactly (camera at the origin, as Camera::update always builds it) and finite rays;
     // any other camera takes the plain brute-force kernel, which reproduces the reference for every input.
     const bool at_origin = cam->origin[0] == 0.0f && cam->origin[1] == 0.0f && cam->origin[2] == 0.0f;
-    if (at_origin && !ctx->force_plain_mode_r && !getenv("RT3_NO_MFMA") && ctx->n_faces > 0) {
-        const size_t lds = (size_t)16 * 4096 + (size_t)kBitmapBytes;
-        RT3_HIP(hipFuncSetAttribute((const void*)k_mode_r_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mode_r_mfma, dim3((npix + kMB - 1) / kMB), dim3(kMB), lds, stream,
+    const bool use_mfma = at_origin && !ctx->force_plain_mode_r && !getenv("RT3_NO_MFMA") && ctx->n_faces > 0;
+    if (use_mfma) {
+        int per_cu = 0;
+        if ((rc = blocks_per_cu(ctx, (const void*)k_mode_r_mfma, kMB, kTiledLdsBytes, &per_cu))) return rc;
+        if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_mode_r_mfma does not fit on a CU");
+    }
+    RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
+    RT3_HIP(hipEventRecord(a, stream));
+    if (use_mfma)
+        hipLaunchKernelGGL(k_mode_r_mfma, dim3((npix + kMB - 1) / kMB), dim3(kMB), kTiledLdsBytes, stream,
                            ctx->d_tri, (const u32x4*)ctx->d_tri_frag, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
-    } else if (at_origin && !ctx->force_plain_mode_r)
+    else if (at_origin && !ctx->force_plain_mode_r)
         hipLaunchKernelGGL(k_mode_r_fast, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                            ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
     else
@@ -457,36 +525,50 @@ int rt3_render(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint32_t hei
     return 0;
 }
 
-int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, void* d_out, void* stream_) {
+int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, uint32_t sample_begin, uint32_t sample_count,
+                                 void* d_out, void* stream_) {
     if (!ctx) return RT3_E_ARG;
     if (!cam || !d_out) return fail(ctx, RT3_E_ARG, "cam / d_out_pixels is NULL");
     int rc = check_params(ctx, p);
     if (rc) return rc;
+    if (sample_count == 0 || (uint64_t)sample_begin + sample_count > p->spp) return fail(ctx, RT3_E_ARG, "sample range outside [0, spp)");
     if (ctx->n_sph == 0 && ctx->n_faces == 0) return fail(ctx, RT3_E_STATE, "no scene: call rt3_set_spheres / rt3_set_mesh first");
+    const bool ref = (p->flags & RT3_FLAG_REFERENCE_PRIMARY) != 0, var = (p->flags & RT3_FLAG_VARIANCE) != 0;
+    if (ref && ctx->n_sph != 0) return fail(ctx, RT3_E_ARG, "RT3_FLAG_REFERENCE_PRIMARY needs a triangle-only scene");
+    if (ctx->n_faces >= (1u << kPairLaneShift) - 32u || ctx->n_sph >= (1u << kPairLaneShift) - 32u) return fail(ctx, RT3_E_ARG, "too many primitives");
     RT3_HIP(hipSetDevice(ctx->device));
     hipStream_t stream = (hipStream_t)stream_;
 
     const uint32_t rows = rt3_rows_owned(p);
     const uint32_t npix = rows * p->width;
+    if (sample_begin != 0) {                                        // a continuation: of this very accumulation?
+        if (!ctx->acc_valid || ctx->acc_done != sample_begin || ctx->acc_npix != npix || !same_bytes(&ctx->acc_params, p, sizeof *p) ||
+            !same_bytes(&ctx->acc_cam, cam, sizeof *cam))
+            return fail(ctx, RT3_E_STATE, "sample_begin does not continue the accumulation held by this context (same camera, params and "
+                                          "samples done are required; start with sample_begin = 0 or rt3_accum_upload)");
+    }
+    ctx->rendered = false;                                          // stats: valid again once every launch below has been issued
+    ctx->acc_valid = false;                                         // accumulation: valid again once this call has been issued completely
     ctx->ev_used = 0;
-    ctx->last_stream = stream;
-    ctx->last_samples = (uint64_t)npix * p->spp;
-    ctx->last_was_path = true;
-    ctx->rendered = true;
-    RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
-    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 64, stream));
-#ifdef RT3_PROFILE
-    RT3_HIP(hipMemsetAsync(ctx->d_casts + 6, 0xFF, 8, stream));
-#endif
-    if (npix == 0) { RT3_HIP(hipEventRecord(ctx->ev_end, stream)); return 0; }
+    if (npix == 0) {
+        RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
+        RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 64, stream));
+        RT3_HIP(hipEventRecord(ctx->ev_end, stream));
+        ctx->last_stream = stream; ctx->last_samples = 0; ctx->last_was_path = true; ctx->rendered = true;
+        ctx->acc_valid = true; ctx->acc_params = *p; ctx->acc_cam = *cam; ctx->acc_done = sample_begin + sample_count; ctx->acc_npix = 0;
+        return 0;
+    }
 
     // batch size: per-sample storage of 12 B per (pixel, sample), capped
     uint64_t per_spp = (uint64_t)npix * sizeof(Rgb);
-    uint32_t batch = (uint32_t)std::min<uint64_t>(p->spp, std::max<uint64_t>(1, ctx->rad_cap_bytes / per_spp));
+    uint32_t batch = (uint32_t)std::min<uint64_t>(sample_count, std::max<uint64_t>(1, ctx->rad_cap_bytes / per_spp));
     batch = (uint32_t)std::min<uint64_t>(batch, 0x7FFF0000ull / npix);
     if (batch == 0) return fail(ctx, RT3_E_ARG, "frame too large for one sample batch");
     if ((rc = ensure(ctx, &ctx->d_rad, &ctx->rad_entries, (size_t)npix * batch))) return rc;
-    if ((rc = ensure(ctx, &ctx->d_accum, &ctx->accum_entries, (size_t)npix))) return rc;
+    if (sample_begin == 0) {
+        if ((rc = ensure(ctx, &ctx->d_accum, &ctx->accum_entries, (size_t)npix))) return rc;
+        if (var && (rc = ensure(ctx, &ctx->d_accum_sq, &ctx->accum_sq_entries, (size_t)npix))) return rc;
+    }
 
     TraceArgs A;
     std::memset(&A, 0, sizeof A);
@@ -518,60 +600,95 @@ int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params
         return fail(ctx, RT3_E_DEVICE, "internal: magic-number division self-check failed");
     A.rad = ctx->d_rad; A.work_counter = ctx->d_work; A.cast_counter = ctx->d_casts;
 
+    // ---- which kernel
+    //   brute         every ray against every primitive (debug switch / RT3_BRUTE=1; REFERENCE_PRIMARY with a camera off the origin or a lens)
+    //   mfma_single   sphere scenes of <= 512 spheres, everything in LDS (the bench kernel)
+    //   mfma tiled    every other scene
+    //   valu          RT3_NO_MFMA=1: the vector-ALU scans (A/B reference)
     using TraceKernel = void (*)(const TraceArgs);
-    const bool has_tri = ctx->n_faces > 0, has_sph = ctx->n_sph > 0;
-    const bool sph_lds = has_sph && ctx->n_sph <= kSphLdsMax;
-    const size_t lds_bytes = sph_lds ? (size_t)ctx->n_sph * sizeof(float4) : 0;
-    const TraceKernel kernel = has_tri ? (has_sph ? (sph_lds ? k_trace<true, true, true> : k_trace<true, true, false>) : k_trace<true, false, false>)
-                                       : (sph_lds ? k_trace<false, true, true> : k_trace<false, true, false>);
-    // candidate filter on the matrix cores (RT3_NO_MFMA=1 keeps the VALU scan, for A/B runs): the all-in-LDS kernel for sphere
-    // scenes of <= 512 spheres, the tiled kernel for everything else
-    const bool use_mfma = !getenv("RT3_NO_MFMA");
-    const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && !getenv("RT3_FORCE_TILED");   // (A/B knob)
-    const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
-    const size_t mfma_lds = mfma_single ? (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)kBitmapBytes
-                                        : (size_t)16 * 4096 + (size_t)kBitmapBytes;
     using TiledKernel = void (*)(const TraceArgs, const u32x4*, const u32x4*);
-    const TiledKernel tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true> : k_trace_mfma_tiled<true, false>) : k_trace_mfma_tiled<false, true>;
-    int per_cu = 0;
-    if (mfma_single) {
-        RT3_HIP(hipFuncSetAttribute((const void*)k_trace_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
-        RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_mfma, kMB, mfma_lds));
+    const bool has_tri = ctx->n_faces > 0, has_sph = ctx->n_sph > 0;
+    const bool cam_at_origin = cam->origin[0] == 0.0f && cam->origin[1] == 0.0f && cam->origin[2] == 0.0f;
+    const bool brute = ctx->force_brute || getenv("RT3_BRUTE") || (ref && !(cam_at_origin && !(p->lens_radius > 0.0f)));
+    const bool use_mfma = !brute && !getenv("RT3_NO_MFMA");
+    const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && !getenv("RT3_FORCE_TILED");   // (A/B knob)
+    const bool sph_lds = has_sph && ctx->n_sph <= kSphLdsMax;
+    const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
+    TraceKernel plain = nullptr;
+    TiledKernel tiled = nullptr;
+    size_t lds = 0;
+    int block = kBlock;
+    const void* kptr = nullptr;
+    if (brute) {
+        plain = ref ? k_trace_brute<true> : k_trace_brute<false>;
+        kptr = (const void*)plain;
+    } else if (mfma_single) {
+        lds = (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)kBitmapBytes;
+        block = kMB;
+        kptr = (const void*)k_trace_mfma;
     } else if (use_mfma) {
-        RT3_HIP(hipFuncSetAttribute((const void*)tiled, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
-        RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, tiled, kMB, mfma_lds));
-    } else RT3_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes));
-    if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_trace does not fit on a CU");
+        tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
+                        : k_trace_mfma_tiled<false, true, false>;
+        lds = kTiledLdsBytes;
+        block = kMB;
+        kptr = (const void*)tiled;
+    } else {
+        lds = sph_lds ? (size_t)ctx->n_sph * sizeof(float4) : 0;
+        plain = has_tri ? (has_sph ? (sph_lds ? k_trace<true, true, true> : k_trace<true, true, false>)
+                                   : (ref ? k_trace<true, false, false, true> : k_trace<true, false, false>))
+                        : (sph_lds ? k_trace<false, true, true> : k_trace<false, true, false>);
+        kptr = (const void*)plain;
+    }
+    int per_cu = 0;
+    if ((rc = blocks_per_cu(ctx, kptr, block, lds, &per_cu))) return rc;
+    if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "the trace kernel does not fit on a CU");
     per_cu = std::min(per_cu, 8);
 
-    for (uint32_t s0 = 0; s0 < p->spp; s0 += batch) {
-        const uint32_t ns = std::min(batch, p->spp - s0);
+    RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
+    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 64, stream));
+#ifdef RT3_PROFILE
+    RT3_HIP(hipMemsetAsync(ctx->d_casts + 6, 0xFF, 8, stream));
+#endif
+    for (uint32_t s0 = sample_begin; s0 < sample_begin + sample_count; s0 += batch) {
+        const uint32_t ns = std::min(batch, sample_begin + sample_count - s0);
         A.s0 = s0;
         A.total = npix * ns;
-        const uint32_t waves_per_block = use_mfma ? kMB / 64 : kBlock / 64;
+        const uint32_t waves_per_block = (uint32_t)block / 64u;
         const uint32_t want_blocks = (A.total + kWorkChunk * waves_per_block - 1) / (kWorkChunk * waves_per_block);
         const uint32_t grid = std::max(1u, std::min<uint32_t>((uint32_t)(ctx->num_cu * per_cu), want_blocks));
         hipEvent_t a, b;
         if ((rc = take_event_pair(ctx, &a, &b))) return rc;
         RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
         RT3_HIP(hipEventRecord(a, stream));
-        if (mfma_single) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), mfma_lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
-        else if (use_mfma) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kMB), mfma_lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag);
-        else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds_bytes, stream, A);
+        if (mfma_single) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
+        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag);
+        else hipLaunchKernelGGL(plain, dim3(grid), dim3(kBlock), lds, stream, A);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipEventRecord(b, stream));
-        hipLaunchKernelGGL(k_accumulate, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                           ctx->d_rad, ctx->d_accum, npix, ns, s0 == 0 ? 1 : 0);
+        const dim3 ag((npix + kBlock - 1) / kBlock), ab(kBlock);
+        if (var) hipLaunchKernelGGL(k_accumulate<true>, ag, ab, 0, stream, ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, npix, ns, s0 == 0 ? 1 : 0);
+        else hipLaunchKernelGGL(k_accumulate<false>, ag, ab, 0, stream, ctx->d_rad, ctx->d_accum, (float4*)nullptr, npix, ns, s0 == 0 ? 1 : 0);
         RT3_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(k_resolve, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
-                       ctx->d_accum, npix, p->spp, p->flags, (uint32_t*)d_out);
+                       ctx->d_accum, npix, sample_begin + sample_count, p->flags, (uint32_t*)d_out);
     RT3_HIP(hipGetLastError());
     RT3_HIP(hipEventRecord(ctx->ev_end, stream));
+    ctx->last_stream = stream;
+    ctx->last_samples = (uint64_t)npix * sample_count;
+    ctx->last_was_path = true;
+    ctx->rendered = true;
+    ctx->acc_valid = true; ctx->acc_params = *p; ctx->acc_cam = *cam; ctx->acc_done = sample_begin + sample_count; ctx->acc_npix = npix;
     return 0;
 }
 
-int rt3_render_path(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, uint32_t* out_pixels) {
+int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, void* d_out, void* stream) {
+    if (!ctx) return RT3_E_ARG;
+    if (!p) return fail(ctx, RT3_E_ARG, "params is NULL");
+    return rt3_render_path_range_device(ctx, cam, p, 0, p->spp, d_out, stream);
+}
+
+int rt3_render_path_range(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, uint32_t sample_begin, uint32_t sample_count, uint32_t* out_pixels) {
     if (!ctx) return RT3_E_ARG;
     if (!out_pixels) return fail(ctx, RT3_E_ARG, "out_pixels is NULL");
     int rc = check_params(ctx, p);
@@ -579,9 +696,98 @@ int rt3_render_path(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, ui
     RT3_HIP(hipSetDevice(ctx->device));
     const size_t npix = (size_t)rt3_rows_owned(p) * p->width;
     if ((rc = ensure(ctx, &ctx->d_out, &ctx->out_entries, std::max<size_t>(npix, 1)))) return rc;
-    if ((rc = rt3_render_path_device(ctx, cam, p, ctx->d_out, ctx->stream))) return rc;
+    if ((rc = rt3_render_path_range_device(ctx, cam, p, sample_begin, sample_count, ctx->d_out, ctx->stream))) return rc;
     if (npix) RT3_HIP(hipMemcpyAsync(out_pixels, ctx->d_out, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
     RT3_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int rt3_render_path(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, uint32_t* out_pixels) {
+    if (!ctx) return RT3_E_ARG;
+    if (!p) return fail(ctx, RT3_E_ARG, "params is NULL");
+    return rt3_render_path_range(ctx, cam, p, 0, p->spp, out_pixels);
+}
+
+// Checkpoint of the accumulation: what rt3_render_path_range keeps between calls, 4 floats per owned pixel.
+int rt3_accum_download(rt3_ctx* ctx, float* sum, float* sum_sq, uint32_t* samples_done) {
+    if (!ctx) return RT3_E_ARG;
+    if (!ctx->acc_valid) return fail(ctx, RT3_E_STATE, "no accumulation on this context");
+    RT3_HIP(hipSetDevice(ctx->device));
+    if (ctx->last_stream != ctx->stream) RT3_HIP(hipStreamSynchronize(ctx->last_stream));   // the render may run on the caller's stream
+    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t bytes = (size_t)ctx->acc_npix * sizeof(float4);
+    if (sum && bytes) RT3_HIP(hipMemcpy(sum, ctx->d_accum, bytes, hipMemcpyDeviceToHost));
+    if (sum_sq) {
+        if (!(ctx->acc_params.flags & RT3_FLAG_VARIANCE)) return fail(ctx, RT3_E_STATE, "the accumulation was not started with RT3_FLAG_VARIANCE");
+        if (bytes) RT3_HIP(hipMemcpy(sum_sq, ctx->d_accum_sq, bytes, hipMemcpyDeviceToHost));
+    }
+    if (samples_done) *samples_done = ctx->acc_done;
+    return 0;
+}
+
+int rt3_accum_upload(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, const float* sum, const float* sum_sq, uint32_t samples_done) {
+    if (!ctx) return RT3_E_ARG;
+    if (!cam || !sum) return fail(ctx, RT3_E_ARG, "cam / sum_rgba is NULL");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (samples_done == 0 || samples_done > p->spp) return fail(ctx, RT3_E_ARG, "samples_done outside (0, spp]");
+    const bool var = (p->flags & RT3_FLAG_VARIANCE) != 0;
+    if (var && !sum_sq) return fail(ctx, RT3_E_ARG, "params ask for RT3_FLAG_VARIANCE: sum_sq_rgba is required");
+    RT3_HIP(hipSetDevice(ctx->device));
+    const uint32_t npix = rt3_rows_owned(p) * p->width;
+    ctx->acc_valid = false;
+    if (npix) {
+        if ((rc = ensure(ctx, &ctx->d_accum, &ctx->accum_entries, (size_t)npix))) return rc;
+        RT3_HIP(hipMemcpy(ctx->d_accum, sum, (size_t)npix * sizeof(float4), hipMemcpyHostToDevice));
+        if (var) {
+            if ((rc = ensure(ctx, &ctx->d_accum_sq, &ctx->accum_sq_entries, (size_t)npix))) return rc;
+            RT3_HIP(hipMemcpy(ctx->d_accum_sq, sum_sq, (size_t)npix * sizeof(float4), hipMemcpyHostToDevice));
+        }
+    }
+    ctx->acc_valid = true; ctx->acc_params = *p; ctx->acc_cam = *cam; ctx->acc_done = samples_done; ctx->acc_npix = npix;
+    return 0;
+}
+
+// The gather of final pixels, device to device.  Row block lb of the shard (tile_rows rows, compact in d_tile)
+// is row block lb * tile_count + tile_index of the frame: one 2-D copy with the tile's pitch on one side and tile_count times that on
+// the other; only the frame's very last row block can be ragged, and it then travels as one more 1-D copy.
+int rt3_gather_rows(rt3_ctx* root, void* d_frame, rt3_ctx* shard, const void* d_tile, const rt3_params* p, void* stream_) {
+    if (!root || !shard) return RT3_E_ARG;
+    rt3_ctx* ctx = shard;
+    if (!d_frame || !d_tile) return fail(ctx, RT3_E_ARG, "rt3_gather_rows: NULL buffer");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    RT3_HIP(hipSetDevice(shard->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : shard->stream;
+    if (root->device != shard->device && !shard->peers_enabled.count(root->device)) {
+        int can = 0;
+        RT3_HIP(hipDeviceCanAccessPeer(&can, shard->device, root->device));
+        if (!can) return fail(ctx, RT3_E_DEVICE, "rt3_gather_rows: no peer access from device " + std::to_string(shard->device) + " to " + std::to_string(root->device));
+        const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { ctx->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return RT3_E_DEVICE; }
+        (void)hipGetLastError();
+        shard->peers_enabled.insert(root->device);
+    }
+    const size_t row_bytes = (size_t)p->width * 4;
+    uint32_t* frame = (uint32_t*)d_frame;
+    const uint32_t* tile = (const uint32_t*)d_tile;
+    if (p->tile_count <= 1) {
+        RT3_HIP(hipMemcpyAsync(frame, tile, row_bytes * p->height, hipMemcpyDeviceToDevice, stream));
+        return 0;
+    }
+    const uint32_t n_blocks_frame = (p->height + p->tile_rows - 1) / p->tile_rows;
+    if (p->tile_index >= n_blocks_frame) return 0;                                  // more shards than row blocks: this one owns nothing
+    const uint32_t my_blocks = (n_blocks_frame - 1 - p->tile_index) / p->tile_count + 1;
+    const uint32_t last_block = (my_blocks - 1) * p->tile_count + p->tile_index;    // frame index of this shard's last block
+    const uint32_t last_rows = std::min(p->tile_rows, p->height - last_block * p->tile_rows);
+    const uint32_t full = last_rows == p->tile_rows ? my_blocks : my_blocks - 1;
+    const size_t block_bytes = row_bytes * p->tile_rows;
+    if (full)
+        RT3_HIP(hipMemcpy2DAsync(frame + (size_t)p->tile_index * p->tile_rows * p->width, block_bytes * p->tile_count, tile, block_bytes,
+                                 block_bytes, full, hipMemcpyDeviceToDevice, stream));
+    if (full != my_blocks)
+        RT3_HIP(hipMemcpyAsync(frame + (size_t)last_block * p->tile_rows * p->width, tile + (size_t)full * p->tile_rows * p->width,
+                               row_bytes * last_rows, hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 
@@ -589,7 +795,7 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
     if (!ctx || !out) return RT3_E_ARG;
     RT3_HIP(hipSetDevice(ctx->device));
     std::memset(out, 0, sizeof *out);
-    if (!ctx->rendered) return fail(ctx, RT3_E_STATE, "no render has been issued on this context");
+    if (!ctx->rendered) return fail(ctx, RT3_E_STATE, "no render has been issued on this context (or the last one failed)");
     RT3_HIP(hipEventSynchronize(ctx->ev_end));
     float ms = 0.0f;
     for (uint32_t i = 0; i < ctx->ev_used; i++) {
@@ -615,6 +821,9 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
         out->ray_casts = counters[0];
         out->prim_tests = counters[0] * ((uint64_t)ctx->n_sph + ctx->n_faces);
         out->mfma_instructions = counters[1];
+#ifndef RT3_PROFILE
+        out->exact_tests = counters[2];
+#endif
     } else {
         out->ray_casts = ctx->last_samples;
         out->prim_tests = ctx->last_samples * (uint64_t)ctx->n_faces;
@@ -630,6 +839,7 @@ int rt3_debug_arith(rt3_ctx* ctx, const float* a, const float* b, uint32_t n, fl
     float* d = nullptr;
     const size_t N = n;
     RT3_HIP(hipMalloc((void**)&d, N * 4 * 11));
+    struct Free { float* p; ~Free() { (void)hipFree(p); } } free_on_return{ d };   // every early return below releases it
     float *da = d, *db = d + N, *ddiv = d + 2 * N, *dsq = d + 3 * N, *dfm = d + 4 * N, *dcs = d + 5 * N, *dsn = d + 6 * N, *dsk = d + 7 * N;
     uint32_t* dpk = (uint32_t*)(d + 10 * N);
     RT3_HIP(hipMemcpy(da, a, N * 4, hipMemcpyHostToDevice));
@@ -644,7 +854,6 @@ int rt3_debug_arith(rt3_ctx* ctx, const float* a, const float* b, uint32_t n, fl
     RT3_HIP(hipMemcpy(sn, dsn, N * 4, hipMemcpyDeviceToHost));
     RT3_HIP(hipMemcpy(sk3, dsk, N * 12, hipMemcpyDeviceToHost));
     RT3_HIP(hipMemcpy(pk, dpk, N * 4, hipMemcpyDeviceToHost));
-    RT3_HIP(hipFree(d));
     return 0;
 }
 

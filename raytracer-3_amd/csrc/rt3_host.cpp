@@ -151,6 +151,10 @@ int rt3_prerender_object(const char* path, const float center[3], float scale, c
             put_vertex(vertices, nv++, origin + scale * Vec3(a, b, c));
         } else if (kind == 'f') {
             if (nf >= n_faces) return RT3_E_ARG;
+            // indices arrive as floats (Object.cpp:157-170); the reference casts blindly, here anything that is not a
+            // representable index is a malformed file (the cast of a negative, non-finite or >= 2^32 float is undefined)
+            auto index_ok = [](float x) { return x >= 0.0f && x < 4294967296.0f; };     // false for NaN
+            if (!index_ok(a) || !index_ok(b) || !index_ok(c)) return RT3_E_IO;
             put_face(faces[nf++], (uint32_t)a, (uint32_t)b, (uint32_t)c, Vec3(), col);
         }
     }
@@ -163,6 +167,7 @@ int rt3_prerender_object(const char* path, const float center[3], float scale, c
     for (uint32_t i = 0; i < nf; i++) {
         rt3_gface& f = faces[i];
         f.v1 -= lowest; f.v2 -= lowest; f.v3 -= lowest;
+        if (f.v1 >= nv || f.v2 >= nv || f.v3 >= nv) return RT3_E_IO;         // a face names a vertex the file does not hold
         const Vec3 a(vertices + 4 * (size_t)f.v1), b(vertices + 4 * (size_t)f.v2), c(vertices + 4 * (size_t)f.v3);
         const Vec3 n = normalize(cross(c - a, b - a));
         const Vec3 shaded = bake(Vec3(f.color), n);

@@ -132,13 +132,67 @@ struct Path {
     uint32_t slot, base, depth;
 };
 
+// The reference's plane + three-edge test of one face (SequentialRenderer.cpp:53-98; hit_vertex, raytracer_v4.glsl:116-153), in
+// its own operation order.  n = (normal, n.p1) as k_commit_mesh stores it.
+//   face_t       the ray parameter of the plane: (n.p1 - n.o) / n.d — Mode X, sign of n.o corrected — or, `literal`, the
+//                reference's own (n.o + n.p1) / n.d (:70, sic), which only means the plane for an origin of 0; false if n.d == 0 (:56)
+//   face_inside  the three edge functions at the point o + t d (:77-98)
+__device__ __forceinline__ bool face_t(const float4 n, float ox, float oy, float oz, float dx, float dy, float dz, bool literal, float& t) {
+    const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
+    if (nd == 0.0f) return false;
+    const float no = dot3(n.x, n.y, n.z, ox, oy, oz);
+    t = (literal ? no + n.w : n.w - no) / nd;
+    return true;
+}
+__device__ __forceinline__ bool face_inside(const float4 n, const float4 p1, const float4 p2, const float4 p3, float ox, float oy, float oz,
+                                            float dx, float dy, float dz, float t) {
+    const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+    float ex, ey, ez, qx, qy, qz, cx, cy, cz;
+    ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
+    ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
+    ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
+    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
+    return -dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f;
+}
+// Both, with the vertices fetched only when t lies in [t_lo, t_hi) (STRICT) or [t_lo, t_hi].
+template <bool STRICT>
+__device__ __forceinline__ bool face_hit(const float4 n, const float4* __restrict__ f, float ox, float oy, float oz, float dx, float dy, float dz,
+                                         float t_lo, float t_hi, bool literal, float& t_out) {
+    float t;
+    if (!face_t(n, ox, oy, oz, dx, dy, dz, literal, t)) return false;
+    if (!(t >= t_lo && (STRICT ? t < t_hi : t <= t_hi))) return false;
+    if (!face_inside(n, f[1], f[2], f[3], ox, oy, oz, dx, dy, dz, t)) return false;
+    t_out = t;
+    return true;
+}
+// Exact ray-sphere test of Mode X (hit_sphere, raytracer_v4.glsl:157-178, unit direction, the book's far-root rule):
+// s = (centre, r^2); true with the accepted root in t when t_min < t.
+__device__ __forceinline__ bool sphere_root(const float4 s, float ox, float oy, float oz, float dx, float dy, float dz, float t_min, float& t_out) {
+    const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
+    const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
+    const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
+    const float disc = fma_(h, h, -c);
+    if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return false;
+    const float sq = __builtin_sqrtf(disc);
+    float t = h - sq;
+    if (!(t > t_min)) t = h + sq;
+    t_out = t;
+    return t > t_min;
+}
+
 __device__ __forceinline__ uint32_t frame_row(const TraceArgs& A, uint32_t local_row) {
     if (A.tile_count <= 1) return local_row;
     const uint32_t lb = fdiv(local_row, A.div_tile_rows), in = local_row - lb * A.tile_rows;
     return (lb * A.tile_count + A.tile_index) * A.tile_rows + in;
 }
 
-// sample -> primary ray (raytracer_v4.glsl:190-214 with the jitter in pixel units), unit direction
+// sample -> primary ray (raytracer_v4.glsl:190-214 with the jitter in pixel units), unit direction.
+// REF (RT3_FLAG_REFERENCE_PRIMARY): the direction stays unnormalised, as SequentialRenderer.cpp:293 leaves it.
+template <bool REF = false>
 __device__ __forceinline__ void start_path(const TraceArgs& A, uint32_t item, Path& P) {
     const uint32_t sb = fdiv(item, A.div_npix), pix = item - sb * A.npix;
     const uint32_t s = A.s0 + sb;
@@ -171,9 +225,12 @@ __device__ __forceinline__ void start_path(const TraceArgs& A, uint32_t item, Pa
         ox = ox + fx; oy = oy + fy; oz = oz + fz;
         rx = rx - fx; ry = ry - fy; rz = rz - fz;
     }
-    const float inv = 1.0f / __builtin_sqrtf(dot3(rx, ry, rz, rx, ry, rz));
     P.ox = ox; P.oy = oy; P.oz = oz;
-    P.dx = rx * inv; P.dy = ry * inv; P.dz = rz * inv;
+    if (REF) { P.dx = rx; P.dy = ry; P.dz = rz; }
+    else {
+        const float inv = 1.0f / __builtin_sqrtf(dot3(rx, ry, rz, rx, ry, rz));
+        P.dx = rx * inv; P.dy = ry * inv; P.dz = rz * inv;
+    }
     P.tr = P.tg = P.tb = 1.0f;
     P.lr = P.lg = P.lb = 0.0f;
     P.slot = item; P.base = base; P.depth = 0;

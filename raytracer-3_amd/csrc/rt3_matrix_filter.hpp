@@ -82,17 +82,16 @@ constexpr float kNeverCandidate = -1e30f, kAlwaysCandidate = 1e30f;
 
 // Ray-side (B operand) fragments of the 64 rays of a wave: [column set (rays 0..31 / 32..63)][operands 0 and 1, operand 2, operand 3].
 struct RayOperands { u32x4 b[2][3]; };
-// v_cvt_pk_bf16_f32 (round to nearest even, two floats -> one dword).  HARDWARE NOTE (measured on MI355X, ROCm 7.2): a VALU
-// instruction that consumes the result straight after the conversion can read a stale register — about one ray in 10^6 lost a
-// candidate, differently in every run, until wait states were added; hipcc's hazard recognizer inserts none for this opcode
-// (it does for v_permlane32_swap).  The conversion is therefore issued through inline asm with its own `s_nop 3`, which also
-// covers the two wait states a following v_permlane32_swap needs; the leading `s_nop 1` is there because the hazard recognizer
-// cannot see into the asm either and so would not separate it from a producer that needs wait states.
-// tests/test_gpu_repeatability.py guards the property.
+// v_cvt_pk_bf16_f32 (round to nearest even, two floats -> one dword), emitted by the COMPILER from a vector conversion, never
+// through inline asm: gfx950 needs two wait states between a vector-ALU write of a VGPR and a v_permlane32_swap that reads it, and
+// hipcc's hazard recognizer only counts them for definitions it can see — an asm block is opaque to it.  (Round 1 issued this opcode
+// from inline asm, lost about one candidate in 10^6 rays, differently per run, and padded the asm with s_nop; profiles/r02_cvt_hazard.md
+// has the ISA of both forms.)  tests/test_gpu_repeatability.py guards the property.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm volatile("s_nop 1\n\tv_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 3" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2 v = { lo, hi };
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 // v_permlane32_swap(x, y): x's upper half-wave <-> y's lower half-wave; set0 = new x, set1 = new y
 __device__ __forceinline__ void swap32(uint32_t x, uint32_t y, uint32_t& set0, uint32_t& set1) {
@@ -222,27 +221,70 @@ __device__ __forceinline__ void mfma_flush_prefetch(uint32_t nz, uint32_t n_bloc
     }
 }
 
-// The reference's plane + three-edge test of one face (same operations, same order as k_trace's face evaluation); returns t or NaN.
-__device__ __forceinline__ bool face_hit(const float4 n, const float4* __restrict__ f, float ox, float oy, float oz, float dx, float dy, float dz,
-                                         float t_lo, float t_hi, float& t_out) {
-    const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
-    if (nd == 0.0f) return false;
-    const float t = (n.w - dot3(n.x, n.y, n.z, ox, oy, oz)) / nd;
-    if (!(t >= t_lo && t <= t_hi)) return false;
-    const float4 p1 = f[1], p2 = f[2], p3 = f[3];
-    const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
-    float ex, ey, ez, qx, qy, qz, cx, cy, cz;
-    ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
-    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
-    ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
-    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
-    ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
-    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return false;
-    t_out = t;
-    return true;
+// ------------------------------------------------------------------------------------------------------
+// Exact tests at full lane utilisation: the candidates of a wave's 64 rays are compacted into a (ray lane, primitive) pair list
+// ------------------------------------------------------------------------------------------------------
+// A ray has few candidates but they cluster (a ray skimming a tessellated wall meets dozens of bounding spheres in one tile while its
+// 63 neighbours meet none), so a loop in which every lane walks its OWN candidates runs at the pace of the unluckiest lane: 5.5 trips per
+// 512-row tile on the 47k-face scene for 0.33 candidates per lane.  Instead each lane pushes its candidates (ballot + prefix count)
+// into a wave-private list in LDS; as soon as 64 pairs are there, all 64 lanes run ONE exact test each — lane k takes pair k, fetches the
+// ray of the owning lane with ds_bpermute and the primitive from global memory — and a hit is folded into the owning ray's record by
+// one 64-bit ds_min: key = (t bits, sphere?, primitive index, sign of t), so the minimum IS the sequential loops' answer (nearest t;
+// on equal t faces before spheres, then the lower index) whatever order the pairs are tested in.  t >= 0 always (t_min >= 0 is checked
+// by the host), so its bit pattern with the sign cleared orders like the number; the sign of a -0.0 rides in the lowest bit.
+constexpr uint32_t kPairCap = 128;                                  // per wave: < 64 left over + one round of <= 64 new pairs
+constexpr uint32_t kPairLaneShift = 26;                             // pair = lane << 26 | primitive row (< 2^26)
+constexpr unsigned long long kKeyNone = 0x7F800000FFFFFFFFull;      // t = +inf: what a real hit (t < inf) always beats
+__device__ __forceinline__ unsigned long long hit_key(float t, uint32_t is_sphere, uint32_t idx) {
+    const uint32_t tb = __float_as_uint(t);
+    return ((unsigned long long)(tb & 0x7FFFFFFFu) << 32) | (is_sphere << 31) | (idx << 1) | (tb >> 31);
+}
+__device__ __forceinline__ void key_decode(unsigned long long key, uint32_t& kind, uint32_t& idx, float& t) {
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    kind = key == kKeyNone ? 0u : 1u + (lo >> 31);
+    idx = (lo & 0x7FFFFFFFu) >> 1;
+    t = __uint_as_float(hi | (lo << 31));
+}
+// Rays of the wave as the exact tests fetch them from the owning lane.
+struct LaneRay { float ox, oy, oz, dx, dy, dz; bool literal; };
+template <bool REF>
+__device__ __forceinline__ LaneRay fetch_ray(const LaneRay& mine, uint32_t src) {
+    const int s = (int)src;
+    LaneRay r;
+    r.ox = __shfl(mine.ox, s); r.oy = __shfl(mine.oy, s); r.oz = __shfl(mine.oz, s);
+    r.dx = __shfl(mine.dx, s); r.dy = __shfl(mine.dy, s); r.dz = __shfl(mine.dz, s);
+    r.literal = REF ? __shfl((int)mine.literal, s) != 0 : false;
+    return r;
+}
+// Pushes this lane's candidates of the tile just scanned (rows b0*32 ..) and runs `test(pair, valid)` — ALL lanes call it, `valid`
+// says whether the lane holds a pair — every time 64 pairs are available.  n_pairs (wave-uniform) carries the remainder to the next tile.
+template <class Test>
+__device__ __forceinline__ void push_and_test(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
+                                              uint32_t& n_pairs, Test&& test) {
+    CandIter it = { nz, 0u, 0u, n_blocks };
+    for (;;) {
+        uint32_t row = 0;
+        const bool have = cand_next(it, bm, row);
+        const unsigned long long m = __ballot(have);
+        if (m == 0ull) break;
+        if (have) pairs[n_pairs + prefix_count(m)] = (lane << kPairLaneShift) | (row0 + row);
+        n_pairs += (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();                            // (LDS serves one wave's requests in order; this only pins the compiler)
+        if (n_pairs >= 64u) {
+            n_pairs -= 64u;
+            test(pairs[n_pairs + lane], true);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+template <class Test>
+__device__ __forceinline__ void test_leftover(uint32_t lane, const uint32_t* pairs, uint32_t& n_pairs, Test&& test) {
+    if (n_pairs != 0u) {
+        const bool valid = lane < n_pairs;
+        test(valid ? pairs[lane] : 0u, valid);
+        __builtin_amdgcn_wave_barrier();
+        n_pairs = 0u;
+    }
 }
 
 // Sphere scenes of <= 512 spheres: everything the loop touches lives in LDS, waves never synchronise after the prologue.
@@ -334,14 +376,20 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
 }
 
 // Any scene: faces (through their bounding spheres) and spheres, streamed through LDS in tiles of 512 rows.  The 16 waves of the
-// workgroup move through the tiles together (two barriers per tile); the exact tests gather their records from global memory.
-// Ties resolve as in the sequential loops: faces before spheres, then the lower index.
-template <bool HAS_TRI, bool HAS_SPH>
+// workgroup move through the tiles together (two barriers per tile); candidates go through the pair list above, the exact tests
+// gather their records from global memory, all 64 lanes at a time.
+// REF: RT3_FLAG_REFERENCE_PRIMARY (camera at the origin, no lens: checked by the host).
+constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;
+template <bool HAS_TRI, bool HAS_SPH, bool REF>
 __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;                                                   // [16][4][64]
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);           // [16][kMB] candidate words
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kMB);   // [kMB] nearest hit of every lane's ray
+    uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kMB);              // [16 waves][kPairCap]
     const uint32_t tid = threadIdx.x, lane = lane_id();
+    uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
+    unsigned long long* keys = s_key + (tid & ~63u);                           // this wave's 64 records
 
     Path P;
     P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
@@ -349,22 +397,23 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
     bool alive = false;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
-    RayStock Q;
-    Q.ox = Q.oy = Q.oz = 0.0f; Q.dx = Q.dy = 0.0f; Q.dz = 1.0f; Q.slot = 0; Q.base = 0; Q.n = 0;
-    unsigned long long casts = 0, mfmas = 0;
+    unsigned long long casts = 0, mfmas = 0, exact = 0;
 
     for (;;) {
-        refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
+        // (no ray stock here: a ray cast costs at least one tile scan, start_path is noise beside it, and the stock's 8 registers are needed)
+        refill_lanes<REF>(A, lane, alive, P, chunk_next, chunk_end, exhausted);
         const unsigned long long live = __ballot(alive);
         if (!__syncthreads_or(live != 0ull ? 1 : 0)) break;                      // the workgroup ends together
         casts += (unsigned long long)__popcll(live);
-        const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+        LaneRay ray = { P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, REF && P.depth == 0 };
+        float ux = ray.dx, uy = ray.dy, uz = ray.dz;                            // what the filter sees: always a unit direction
+        if (REF && ray.literal) { const float inv = 1.0f / __builtin_sqrtf(dot3(ux, uy, uz, ux, uy, uz)); ux = ux * inv; uy = uy * inv; uz = uz * inv; }
         RayOperands R;
-        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, R);
-        float tbest = __builtin_inff();
-        uint32_t ibest = 0, kind = 0;
+        build_ray_operands(ray.ox, ray.oy, ray.oz, ux, uy, uz, alive, R);
+        keys[lane] = kKeyNone;
+        uint32_t n_pairs = 0;
 
-        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& fetch_row, auto&& eval_row) {
+        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& test) {
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
             for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
                 const uint32_t nb = min(16u, total_blocks - b0);
@@ -372,48 +421,62 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
                 for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = frags[(size_t)b0 * 256 + k];
                 __syncthreads();
                 const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-                mfma_flush_prefetch(nz, nb, s_bm + tid, [&](uint32_t row) { return fetch_row(b0 * 32u + row); },
-                                    [&](uint32_t row, const float4 rec) { eval_row(b0 * 32u + row, rec); });
+                push_and_test(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
                 mfmas += nb * 8ull;
             }
+            test_leftover(lane, pairs, n_pairs, test);
         };
-        if (HAS_TRI)
-            pass(tri_frags, A.n_tri, [&](uint32_t j) { return A.tri[(size_t)min(j, A.n_tri - 1u) * 4]; }, [&](uint32_t j, const float4 n) {
-                if (j >= A.n_tri) return;
+        if (HAS_TRI) {
+            auto test = [&](uint32_t pair, bool valid) {
+                const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
+                const LaneRay r = fetch_ray<REF>(ray, src);
+                exact += (unsigned long long)__popcll(__ballot(valid));
+                if (!valid || j >= A.n_tri) return;
+                const float4* f = A.tri + (size_t)j * 4;
+                const float t_hi = __uint_as_float((uint32_t)(keys[src] >> 32));   // the ray's best t so far: farther faces need no edge tests
                 float t;
-                if (!face_hit(n, A.tri + (size_t)j * 4, ox, oy, oz, dx, dy, dz, A.t_min, tbest, t)) return;
-                if (t < tbest || j < ibest) { tbest = t; ibest = j; kind = 1; }      // t <= tbest here: equal t keeps the lower face index
-            });
-        if (HAS_SPH)
-            pass(sph_frags, A.n_sph, [&](uint32_t j) { return A.sph[min(j, A.n_sph - 1u)]; }, [&](uint32_t j, const float4 s) {
-                if (j >= A.n_sph) return;
-                const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-                const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
-                const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
-                const float disc = fma_(h, h, -c);
-                if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return;
-                const float sq = __builtin_sqrtf(disc);
-                float t = h - sq;
-                if (!(t > A.t_min)) t = h + sq;
-                if (t > A.t_min && (t < tbest || (t == tbest && kind == 2 && j < ibest))) { tbest = t; ibest = j; kind = 2; }
-            });
-        shade_lane<HAS_TRI, HAS_SPH>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
+                if (!face_hit<false>(f[0], f, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t_hi, r.literal, t)) return;
+                if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
+            };
+            pass(tri_frags, A.n_tri, test);
+        }
+        if (HAS_SPH) {
+            auto test = [&](uint32_t pair, bool valid) {
+                const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
+                const LaneRay r = fetch_ray<false>(ray, src);
+                exact += (unsigned long long)__popcll(__ballot(valid));
+                if (!valid || j >= A.n_sph) return;
+                float t;
+                if (sphere_root(A.sph[j], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 1u, j));
+            };
+            pass(sph_frags, A.n_sph, test);
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t kind, ibest;
+        float tbest;
+        key_decode(keys[lane], kind, ibest, tbest);
+        shade_lane<HAS_TRI, HAS_SPH, REF>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
     }
-    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, mfmas); }
+    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, mfmas); atomicAdd(A.cast_counter + 2, exact); }
 }
 
 // Mode R through the matrix-core filter (camera at the origin, as k_mode_r_fast): one thread per pixel, 1024 pixels per
-// workgroup, face bounding spheres streamed through LDS in tiles of 512; the reference's literal test runs on the candidates.
+// workgroup, face bounding spheres streamed through LDS in tiles of 512; the reference's literal test (SequentialRenderer.cpp:53-98)
+// runs on the candidates through the pair list; "t >= min_t rejects" of :71 == the lowest index wins ties == the key order.
 __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ tri, const u32x4* __restrict__ tri_frags,
                                                     const float4* __restrict__ face_rgb, uint32_t n_faces, CamDev cam,
                                                     uint32_t width, uint32_t height, uint32_t* __restrict__ out) {
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kMB);
+    uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kMB);
     const uint32_t tid = threadIdx.x, lane = lane_id();
+    uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
+    unsigned long long* keys = s_key + (tid & ~63u);
     const uint32_t pixel = blockIdx.x * kMB + tid;
-    const bool valid = pixel < width * height;
-    const uint32_t x = valid ? pixel % width : 0u, y = valid ? pixel / width : 0u;
+    const bool valid_px = pixel < width * height;
+    const uint32_t x = valid_px ? pixel % width : 0u, y = valid_px ? pixel / width : 0u;
     const float u = (float)((double)(float)x / ((double)(float)width - 1.0));
     const float v = (float)((double)(float)(height - 1 - y) / ((double)(float)height - 1.0));
     const float ox = cam.ox, oy = cam.oy, oz = cam.oz;              // all zero (checked by the host)
@@ -422,44 +485,38 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
     const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
     const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));     // unit direction for the filter only
     RayOperands R;
-    build_ray_operands(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid, R);
+    build_ray_operands(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid_px, R);
+    const LaneRay ray = { ox, oy, oz, dx, dy, dz, true };
+    keys[lane] = kKeyNone;
+    uint32_t n_pairs = 0;
 
-    uint32_t min_i = 0;
-    float min_t = __builtin_inff();
+    auto test = [&](uint32_t pair, bool valid) {
+        const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
+        const LaneRay r = fetch_ray<false>(ray, src);
+        if (!valid || j >= n_faces) return;
+        const float4* f = tri + (size_t)j * 4;
+        const float t_hi = __uint_as_float((uint32_t)(keys[src] >> 32));
+        float t;
+        if (!face_hit<false>(f[0], f, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, 0.0f, t_hi, true, t)) return;     // :70-71: literal formula, t < 0 rejects
+        if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
+    };
     const uint32_t total_blocks = (n_faces + 31u) / 32u;
     for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
         const uint32_t nb = min(16u, total_blocks - b0);
         __syncthreads();
         for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = tri_frags[(size_t)b0 * 256 + k];
         __syncthreads();
-        auto eval = [&](uint32_t row, const float4 n) {
-            const uint32_t j = b0 * 32u + row;
-            if (j >= n_faces) return;
-            const float4* f = tri + (size_t)j * 4;
-            const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);       // SequentialRenderer.cpp:56
-            if (nd == 0.0f) return;
-            const float t = (dot3(n.x, n.y, n.z, ox, oy, oz) + n.w) / nd;      // :70
-            if (t < 0.0f || t > min_t) return;                      // :71, with equality kept for the index rule below
-            const float4 p1 = f[1], p2 = f[2], p3 = f[3];
-            const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
-            float ex, ey, ez, qx, qy, qz, cx, cy, cz;
-            ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
-            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
-            ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
-            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
-            ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
-            cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-            if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
-            if (t < min_t || j < min_i) { min_i = j; min_t = t; }   // "t >= min_t rejects" of :71 == the lowest index wins ties
-        };
         const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-        mfma_flush_prefetch(nz, nb, s_bm + tid, [&](uint32_t row) { return tri[(size_t)min(b0 * 32u + row, n_faces - 1u) * 4]; }, eval);
+        push_and_test(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
     }
-    if (!valid) return;
+    test_leftover(lane, pairs, n_pairs, test);
+    __builtin_amdgcn_wave_barrier();
+    if (!valid_px) return;
+    uint32_t kind, min_i;
+    float min_t;
+    key_decode(keys[lane], kind, min_i, min_t);
     float r, g, b;
-    if (min_t < __builtin_inff()) { const float4 c = face_rgb[min_i]; r = c.x; g = c.y; b = c.z; }
+    if (kind != 0u) { const float4 c = face_rgb[min_i]; r = c.x; g = c.y; b = c.z; }
     else sky(dx, dy, dz, r, g, b);
     out[pixel] = pack_pixel(r, g, b);
 }

@@ -8,6 +8,7 @@ namespace {
 // scene does not pay registers or code for the triangle path.
 // Refill: lanes whose path ended take the next samples of the wave's chunk (ballot + prefix count); a chunk of
 // kWorkChunk samples is fetched from the global queue with one atomic when the wave runs dry.
+template <bool REF = false>
 __device__ __forceinline__ void refill_lanes(const TraceArgs& A, uint32_t lane, bool& alive, Path& P, uint32_t& chunk_next,
                                              uint32_t& chunk_end, bool& exhausted) {
     const unsigned long long need = __ballot(!alive);
@@ -29,7 +30,7 @@ __device__ __forceinline__ void refill_lanes(const TraceArgs& A, uint32_t lane, 
             chunk_next += k;
             taken += k;
         }
-        if (item != 0xFFFFFFFFu) { start_path(A, item, P); alive = true; }
+        if (item != 0xFFFFFFFFu) { start_path<REF>(A, item, P); alive = true; }
     }
 }
 
@@ -47,6 +48,7 @@ __device__ __forceinline__ void stock_pop(const RayStock& Q, uint32_t src, bool 
         alive = true;
     }
 }
+template <bool REF = false>
 __device__ __forceinline__ void refill_from_stock(const TraceArgs& A, uint32_t lane, bool& alive, Path& P, RayStock& Q, uint32_t& chunk_next,
                                                   uint32_t& chunk_end, bool& exhausted) {
     const unsigned long long need = __ballot(!alive);
@@ -73,7 +75,7 @@ __device__ __forceinline__ void refill_from_stock(const TraceArgs& A, uint32_t l
         }
         const uint32_t n_new = min(64u, chunk_end - chunk_next);
         Path T;
-        start_path(A, min(chunk_next + lane, chunk_end - 1u), T);
+        start_path<REF>(A, min(chunk_next + lane, chunk_end - 1u), T);
         Q.ox = T.ox; Q.oy = T.oy; Q.oz = T.oz; Q.dx = T.dx; Q.dy = T.dy; Q.dz = T.dz; Q.slot = T.slot; Q.base = T.base;
         Q.n = n_new;
         chunk_next += n_new;
@@ -82,10 +84,13 @@ __device__ __forceinline__ void refill_from_stock(const TraceArgs& A, uint32_t l
 
 // Shade / scatter one ray cast of every live lane (book materials).  kind: 0 miss, 1 face, 2 sphere.
 // The four per-sphere arrays read at a hit are parameters: global memory in k_trace, LDS copies in k_trace_mfma.
-template <bool HAS_TRI, bool HAS_SPH>
+// REF (RT3_FLAG_REFERENCE_PRIMARY): at ray cast 0 the direction is the reference's unnormalised one — the sky and the hit point use
+// it as it is (SequentialRenderer.cpp:77,105-107); the scatter formulas then get the unit direction.
+template <bool HAS_TRI, bool HAS_SPH, bool REF = false>
 __device__ __forceinline__ void shade_lane(const TraceArgs& A, Path& P, bool& alive, uint32_t kind, uint32_t ibest, float tbest,
                                            const float4* sph, const float* sph_invr, const float4* sph_mat, const uint32_t* sph_kind) {
-    const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+    const float ox = P.ox, oy = P.oy, oz = P.oz;
+    float dx = P.dx, dy = P.dy, dz = P.dz;
     if (alive) {
         bool done = false;
         if (kind == 0) {
@@ -116,6 +121,10 @@ __device__ __forceinline__ void shade_lane(const TraceArgs& A, Path& P, bool& al
             } else if (P.depth + 1 == A.max_depth) {
                 done = true;
             } else {
+                if (REF && P.depth == 0) {
+                    const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+                    dx = dx * inv; dy = dy * inv; dz = dz * inv;
+                }
                 const bool front = dotf(dx, dy, dz, nx, ny, nz) < 0.0f;
                 if (!front) { nx = -nx; ny = -ny; nz = -nz; }           // (the dot product is recomputed with the flipped normal below:
                 const uint32_t ctr = 1u + 8u * (P.depth + 1u);

@@ -4,17 +4,24 @@
 
 namespace {
 
-// reduce pass (what reduce_v1.glsl:66-76 was meant to be): samples are summed per pixel in sample order.
-__global__ __launch_bounds__(kBlock) void k_accumulate(const Rgb* __restrict__ rad, float4* __restrict__ accum,
+// reduce pass (what reduce_v1.glsl:66-76 was meant to be): samples are summed per pixel in sample order.  `accum` persists between
+// launches (sample batches of one render, and the calls of a progressive render: rt3_render_path_range); VAR also keeps the sums of
+// squares sq = fma(L, L, sq), in the same order (RT3_FLAG_VARIANCE).
+template <bool VAR>
+__global__ __launch_bounds__(kBlock) void k_accumulate(const Rgb* __restrict__ rad, float4* __restrict__ accum, float4* __restrict__ accum_sq,
                                                       uint32_t npix, uint32_t ns, int first) {
     const uint32_t pix = blockIdx.x * kBlock + threadIdx.x;
     if (pix >= npix) return;
-    float4 a = first ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : accum[pix];
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 a = first ? zero : accum[pix];
+    float4 q = (VAR && !first) ? accum_sq[pix] : zero;
     for (uint32_t s = 0; s < ns; s++) {
         const Rgb r = rad[(size_t)s * npix + pix];
         a.x = a.x + r.r; a.y = a.y + r.g; a.z = a.z + r.b;
+        if (VAR) { q.x = fma_(r.r, r.r, q.x); q.y = fma_(r.g, r.g, q.y); q.z = fma_(r.b, r.b, q.z); }
     }
     accum[pix] = a;
+    if (VAR) accum_sq[pix] = q;
 }
 __global__ __launch_bounds__(kBlock) void k_resolve(const float4* __restrict__ accum, uint32_t npix, uint32_t spp,
                                                    uint32_t flags, uint32_t* __restrict__ out) {

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_mode_r_fast(const float4* __restrict
 
 // SPH_LDS: the sphere array (<= kSphLdsMax entries) is also copied to LDS once per block, for the per-lane gathers of
 // the exact evaluation (an LDS gather costs ~64 cycles, a global one an L2 round trip per candidate).
-template <bool HAS_TRI, bool HAS_SPH, bool SPH_LDS>
+template <bool HAS_TRI, bool HAS_SPH, bool SPH_LDS, bool REF = false>
 __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
     __shared__ uint32_t cand[kCandSlots * kBlock];                  // per-lane candidate queues, [slot][thread]
     extern __shared__ float4 s_sph[];                               // SPH_LDS only
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
     unsigned long long casts = 0;                                   // wave-uniform
 
     for (;;) {
-        refill_lanes(A, lane, alive, P, chunk_next, chunk_end, exhausted);
+        refill_lanes<REF>(A, lane, alive, P, chunk_next, chunk_end, exhausted);
         if (__ballot(alive) == 0ull) break;                         // waves are independent: no block-level barrier anywhere
         casts += (unsigned long long)__popcll(__ballot(alive));
 
@@ -220,29 +220,18 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
         // Faces: hit_vertex, raytracer_v4.glsl:116-153 (= ray_color's test, SequentialRenderer.cpp:53-98, with the sign of
         // n.o corrected).  The hot loop tests the ray against a slightly inflated bounding sphere of every face; the
         // reference's plane + three-edge test, in its own operation order, runs only for the faces that survive.
+        // REF: ray cast 0 keeps the reference's unnormalised direction and literal formula; the scan sees the unit direction
+        // (the host sends such a render here only when the camera sits at the origin, where the bound is valid for that formula).
         if (HAS_TRI) {
-            const uint32_t t0 = 0;
             if (alive) {
-                scan_tile<true, true>(as_scene(A.tri_bound), A.n_tri, cand, tid, ox, oy, oz, dx, dy, dz,
-                                [&](uint32_t j) { return A.tri[(size_t)(t0 + j) * 4]; }, [&](uint32_t j, const float4 n) {
-                    const float4* f = A.tri + (size_t)(t0 + j) * 4;
-                    const float nd = dot3(dx, dy, dz, n.x, n.y, n.z);
-                    if (nd == 0.0f) return;
-                    const float t = (n.w - dot3(n.x, n.y, n.z, ox, oy, oz)) / nd;
-                    if (!(t >= A.t_min && t < tbest)) return;
-                    const float4 p1 = f[1], p2 = f[2], p3 = f[3];
-                    const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
-                    float ex, ey, ez, qx, qy, qz, cx, cy, cz;
-                    ex = p2.x - p1.x; ey = p2.y - p1.y; ez = p2.z - p1.z; qx = hx - p1.x; qy = hy - p1.y; qz = hz - p1.z;
-                    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
-                    ex = p3.x - p2.x; ey = p3.y - p2.y; ez = p3.z - p2.z; qx = hx - p2.x; qy = hy - p2.y; qz = hz - p2.z;
-                    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
-                    ex = p1.x - p3.x; ey = p1.y - p3.y; ez = p1.z - p3.z; qx = hx - p3.x; qy = hy - p3.y; qz = hz - p3.z;
-                    cx = ey * qz - qy * ez; cy = ez * qx - qz * ex; cz = ex * qy - qx * ey;
-                    if (!(-dot3(n.x, n.y, n.z, cx, cy, cz) >= 0.0f)) return;
-                    tbest = t; ibest = t0 + j; kind = 1;
+                const bool ref0 = REF && P.depth == 0;
+                float ux = dx, uy = dy, uz = dz;
+                if (ref0) { const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz)); ux = dx * inv; uy = dy * inv; uz = dz * inv; }
+                scan_tile<true, true>(as_scene(A.tri_bound), A.n_tri, cand, tid, ox, oy, oz, ux, uy, uz,
+                                [&](uint32_t j) { return A.tri[(size_t)j * 4]; }, [&](uint32_t j, const float4 n) {
+                    float t;
+                    if (!face_hit<true>(n, A.tri + (size_t)j * 4, ox, oy, oz, dx, dy, dz, A.t_min, tbest, ref0, t)) return;
+                    tbest = t; ibest = j; kind = 1;
                 });
             }
         }
@@ -250,24 +239,60 @@ __global__ __launch_bounds__(kBlock) void k_trace(const TraceArgs A) {
         // Analytic spheres: hit_sphere, raytracer_v4.glsl:157-178 with a unit direction.  Exact roots only for the few
         // spheres whose line the ray crosses; the exact candidate rule of DESIGN.md §4.4 is re-checked there.
         if (HAS_SPH) {
-            const uint32_t t0 = 0;
             if (alive) {
                 scan_tile<false, false>(as_scene(A.sph), A.n_sph, cand, tid, ox, oy, oz, dx, dy, dz,
                                  [&](uint32_t j) { return SPH_LDS ? s_sph[j] : A.sph[j]; }, [&](uint32_t j, const float4 s) {
-                    const float cx = s.x - ox, cy = s.y - oy, cz = s.z - oz;
-                    const float h = fma_(cz, dz, fma_(cy, dy, cx * dx));
-                    const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -s.w)));
-                    const float disc = fma_(h, h, -c);
-                    if (!((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)))) return;
-                    const float sq = __builtin_sqrtf(disc);
-                    float t = h - sq;
-                    if (!(t > A.t_min)) t = h + sq;
-                    if (t > A.t_min && t < tbest) { tbest = t; ibest = t0 + j; kind = 2; }
+                    float t;
+                    if (sphere_root(s, ox, oy, oz, dx, dy, dz, A.t_min, t) && t < tbest) { tbest = t; ibest = j; kind = 2; }
                 });
             }
         }
 
-        shade_lane<HAS_TRI, HAS_SPH>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
+        shade_lane<HAS_TRI, HAS_SPH, REF>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
+    }
+    if (lane == 0 && casts != 0) atomicAdd(A.cast_counter, casts);
+}
+
+// Mode X with NO candidate filter: every ray against every face, then every sphere, in index order, exactly as the sequential
+// oracle loops — no bounding spheres, no matrix cores, no queues.  It is the on-GPU arbiter for the filtered kernels (tests,
+// tools/fuzz_filter.py; rt3_debug_force_brute / RT3_BRUTE=1) and the only kernel that can serve RT3_FLAG_REFERENCE_PRIMARY with a
+// camera off the origin (the reference's literal formula then puts the "hit point" off the face's plane, where no bound holds).
+// Scene records are wave-uniform loads through the constant address space (scalar cache); one path per lane, refill by ballot.
+template <bool REF>
+__global__ __launch_bounds__(kBlock) void k_trace_brute(const TraceArgs A) {
+    const uint32_t lane = lane_id();
+    Path P;
+    P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
+    P.tr = P.tg = P.tb = 0.0f; P.lr = P.lg = P.lb = 0.0f; P.slot = 0; P.base = 0; P.depth = 0;
+    bool alive = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    unsigned long long casts = 0;
+    const scene_ptr tri = as_scene(A.tri), sph = as_scene(A.sph);
+    auto f4 = [](const f32x4 v) { return make_float4(v.x, v.y, v.z, v.w); };
+
+    for (;;) {
+        refill_lanes<REF>(A, lane, alive, P, chunk_next, chunk_end, exhausted);
+        if (__ballot(alive) == 0ull) break;
+        casts += (unsigned long long)__popcll(__ballot(alive));
+        float tbest = __builtin_inff();
+        uint32_t ibest = 0, kind = 0;
+        const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
+        const bool ref0 = REF && P.depth == 0;
+        for (uint32_t j = 0; j < A.n_tri; j++) {
+            const float4 n = f4(tri[4 * (size_t)j]), p1 = f4(tri[4 * (size_t)j + 1]), p2 = f4(tri[4 * (size_t)j + 2]), p3 = f4(tri[4 * (size_t)j + 3]);
+            float t;
+            if (!alive || !face_t(n, ox, oy, oz, dx, dy, dz, ref0, t)) continue;
+            if (!(t >= A.t_min && t < tbest)) continue;
+            if (!face_inside(n, p1, p2, p3, ox, oy, oz, dx, dy, dz, t)) continue;
+            tbest = t; ibest = j; kind = 1;
+        }
+        for (uint32_t j = 0; j < A.n_sph; j++) {
+            const float4 s = f4(sph[j]);
+            float t;
+            if (alive && sphere_root(s, ox, oy, oz, dx, dy, dz, A.t_min, t) && t < tbest) { tbest = t; ibest = j; kind = 2; }
+        }
+        shade_lane<true, true, REF>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);   // kind says which arrays to read
     }
     if (lane == 0 && casts != 0) atomicAdd(A.cast_counter, casts);
 }

@@ -253,22 +253,41 @@ void HipRenderer::render(Camera& camera) const {
         if (rt3_render(ctx[0], &cam, w, h, out) != 0) throw Fatal(rt3_last_error(ctx[0]));
         return;
     }
-    // Mode X: interleaved row blocks over the GPUs, one host thread per device, rows scattered into the frame
+    // Mode X: interleaved row blocks over the GPUs (tiling intent: BlockInfo, raytracer_v4.glsl:70-79).  Every device renders its rows
+    // into a tile in its OWN memory; the tiles then travel device to device into device 0's frame at their interleaved row offsets
+    // (rt3_gather_rows: one strided peer copy per device over xGMI, queued on the rendering stream right behind the resolve kernel, so
+    // a device that finishes early ships its rows while the others still trace) and the assembled frame leaves device 0 in one copy.
+    // No pixel passes through host memory before that.  One host thread per device only issues the (asynchronous) work.
     const uint32_t n = (uint32_t)ctx.size();
+    if (n == 1) {
+        rt3_params p{ w, h, path.spp, path.max_depth, path.seed, path.flags, path.lens_radius, path.t_min, path.tile_rows, 0, 1 };
+        if (rt3_render_path(ctx[0], &cam, &p, out) != 0) throw Fatal(rt3_last_error(ctx[0]));
+        return;
+    }
+    struct DeviceBuffer {                                // freed on every way out
+        rt3_ctx* c; void* p;
+        ~DeviceBuffer() { rt3_device_free(c, p); }
+    };
+    DeviceBuffer frame{ ctx[0], rt3_device_alloc_words(ctx[0], (uint64_t)w * h) };
+    if (!frame.p) throw Fatal(rt3_last_error(ctx[0]));
     std::vector<std::string> errors(n);
     std::vector<std::thread> workers;
     for (uint32_t i = 0; i < n; i++) {
         workers.emplace_back([&, i]() {
             rt3_params p{ w, h, path.spp, path.max_depth, path.seed, path.flags, path.lens_radius, path.t_min, path.tile_rows, i, n };
             const uint32_t rows = rt3_rows_owned(&p);
-            std::vector<uint32_t> tile((size_t)rows * w);
-            if (rt3_render_path(ctx[i], &cam, &p, tile.data()) != 0) { errors[i] = rt3_last_error(ctx[i]); return; }
-            for (uint32_t r = 0; r < rows; r++)
-                std::memcpy(out + (size_t)rt3_row_of_local(&p, r) * w, tile.data() + (size_t)r * w, 4 * (size_t)w);
+            if (rows == 0) return;
+            DeviceBuffer tile{ ctx[i], rt3_device_alloc_words(ctx[i], (uint64_t)rows * w) };
+            if (!tile.p) { errors[i] = rt3_last_error(ctx[i]); return; }
+            if (rt3_render_path_device(ctx[i], &cam, &p, tile.p, rt3_stream(ctx[i])) != 0 ||
+                rt3_gather_rows(ctx[0], frame.p, ctx[i], tile.p, &p, rt3_stream(ctx[i])) != 0 ||
+                rt3_synchronize(ctx[i]) != 0)
+                errors[i] = rt3_last_error(ctx[i]);
         });
     }
     for (std::thread& t : workers) t.join();
     for (const std::string& e : errors) if (!e.empty()) throw Fatal(e);
+    if (rt3_device_read_words(ctx[0], frame.p, (uint64_t)w * h, out) != 0) throw Fatal(rt3_last_error(ctx[0]));
 }
 
 rt3_stats HipRenderer::stats() const {

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <iostream>
 #include <limits>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -141,6 +142,15 @@ int main(int argc, const char** argv) {
     try {
         std::vector<int> devices;
         for (uint32_t i = 0; i < (opt.gpus ? opt.gpus : 1); i++) devices.push_back((int)i);
+        // RT3_DEVICE_LIST="0,0,0" (testing aid): the device behind each of the --gpus shards, so that the multi-device path —
+        // device tiles, device-to-device gather into shard 0's frame — can be exercised on a box with a single GPU
+        if (const char* list = std::getenv("RT3_DEVICE_LIST")) {
+            devices.clear();
+            std::stringstream ss(list);
+            std::string item;
+            while (std::getline(ss, item, ',')) if (!item.empty()) devices.push_back(std::atoi(item.c_str()));
+            if (devices.empty()) devices.push_back(0);
+        }
         HipRenderer renderer(devices);
         renderer.set_gpu_prerender(opt.gpu_prerender);
         Camera cam;

@@ -19,7 +19,7 @@ MATERIAL = np.dtype([("rgb", "<f4", 3), ("param", "<f4"), ("kind", "<u4")])
 assert GFACE.itemsize == 48 and MATERIAL.itemsize == 20
 
 MAT_FLAT, MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
-FLAG_GAMMA2, FLAG_BLACK = 1, 2
+FLAG_GAMMA2, FLAG_BLACK, FLAG_REFERENCE_PRIMARY, FLAG_VARIANCE = 1, 2, 4, 8
 
 
 class Camera(C.Structure):
@@ -60,6 +60,7 @@ def lib():
         _lib.oracle_random_float.argtypes = [C.c_uint32]
         _lib.oracle_frame_ppm_bytes.restype = C.c_uint64
         _lib.oracle_render_path.restype = C.c_uint64
+        _lib.oracle_render_path_range.restype = C.c_uint64
         _lib.oracle_rows_owned.restype = C.c_uint32
     return _lib
 
@@ -160,6 +161,35 @@ def render_path(cam, params, spheres=None, smats=None, faces=None, verts=None, f
     if want_sum:
         return out, osum, casts
     return out, casts
+
+
+def render_path_range(cam, params, s_begin, s_count, acc=None, sq=None, spheres=None, smats=None, faces=None, verts=None, fmats=None,
+                      threads=8):
+    """Progressive oracle render: samples [s_begin, s_begin + s_count) added to (acc, sq) — arrays [rows, w, 4] float32, created
+    when s_begin == 0.  Returns (pixels over the samples so far, acc, sq, ray casts); sq only with FLAG_VARIANCE."""
+    ns = 0 if spheres is None else len(spheres)
+    nf = 0 if faces is None else len(faces)
+    if spheres is not None:
+        spheres = np.ascontiguousarray(spheres, np.float32)
+        smats = np.ascontiguousarray(smats)
+    if faces is not None:
+        faces = np.ascontiguousarray(faces)
+        verts = np.ascontiguousarray(verts, np.float32)
+        if fmats is not None:
+            fmats = np.ascontiguousarray(fmats)
+    rows = lib().oracle_rows_owned(C.byref(params))
+    out = np.zeros((rows, params.width), np.uint32)
+    if acc is None:
+        assert s_begin == 0
+        acc = np.zeros((rows, params.width, 4), np.float32)
+    if sq is None and (params.flags & FLAG_VARIANCE):
+        assert s_begin == 0
+        sq = np.zeros((rows, params.width, 4), np.float32)
+    casts = lib().oracle_render_path_range(_p(faces), C.c_uint32(nf), _p(verts), _p(fmats), _p(spheres), _p(smats), C.c_uint32(ns),
+                                           C.byref(cam), C.byref(params), C.c_uint32(s_begin), C.c_uint32(s_count), _p(out), _p(acc),
+                                           _p(sq), C.c_int(threads))
+    assert casts != 0xFFFFFFFFFFFFFFFF, "oracle: unsupported combination"
+    return out, acc, sq, casts
 
 
 def ppm_bytes(pixels):

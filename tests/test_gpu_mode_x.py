@@ -96,6 +96,27 @@ def test_config2_full_frame_equals_the_oracle_frame(rt3, renderer):
     assert renderer.stats().ray_casts == gold["ray_casts"]
 
 
+def test_config3_4k_1024spp_rows_against_the_oracle_and_the_union_of_eight_shards(rt3, renderer):
+    """BASELINE.json configs[2]: the same scene at 3840x2160, 1024 spp, depth 50, framebuffer tiled across 8 GPUs.  Full size on the
+    one GPU of the box: (a) two full-width rows of the whole frame against the oracle, bit for bit; (b) the eight shards of the
+    N = 8 run (single-row interleave, as bench.py shards) rendered one after the other on this device reassemble to the whole
+    frame bitwise — the image does not depend on the number of GPUs (tiling intent: raytracer_v4.glsl:70-79,193-194)."""
+    cr, mats = rt3.scene_weekend(42)
+    W, H = 3840, 2160
+    cam = rt3.weekend_camera(W, H)
+    base = dict(width=W, height=H, spp=1024, max_depth=50, seed=1, flags=1, lens_radius=0.05)
+    case = dict(spheres=cr, smats=mats, cam=cam.c, params=base)
+    whole = hip_render(renderer, case)
+    st = renderer.stats()
+    assert st.samples == W * H * 1024 and st.launches > 1                      # 8.5e9 samples: several sample batches
+    want, _ = oracle_render(case, threads=16, tile_rows=1, tile_index=700, tile_count=1080)    # rows 700 and 1780
+    assert_same(np.stack([whole[700], whole[1780]]), want, "config 3 rows")
+    plist = [rt3.make_params(**dict(base, tile_rows=1, tile_index=i, tile_count=8)) for i in range(8)]
+    tiles = [hip_render(renderer, case, upload=False, tile_rows=1, tile_index=i, tile_count=8) for i in range(8)]
+    assert all(t.shape == (H // 8, W) for t in tiles)
+    assert_same(rt3.deinterleave(tiles, plist, H, W), whole, "config 3: union of the 8 shards")
+
+
 def test_config4_many_spheres_multi_tile(rt3, renderer):
     """BASELINE.json configs[3] shape: 100k Lambertian spheres streamed through LDS in 1024-sphere tiles; 1920x1080 at
     reduced spp, two full-width rows against the oracle + shard invariance of the whole frame."""
@@ -110,6 +131,22 @@ def test_config4_many_spheres_multi_tile(rt3, renderer):
     plist = [rt3.make_params(**dict(base, tile_rows=8, tile_index=i, tile_count=3)) for i in range(3)]
     tiles = [hip_render(renderer, case, upload=False, tile_rows=8, tile_index=i, tile_count=3) for i in range(3)]
     assert_same(rt3.deinterleave(tiles, plist, H, W), whole, "config 4 sharded")
+
+
+def test_config4_depth_50_rows_against_the_oracle(rt3, renderer):
+    """BASELINE.json configs[3] with its own depth (50) at full width: paths bounce through the 196 LDS tiles up to 50 times.
+    Two full-width rows (4 spp of the 256) against the oracle, from a render of just those rows and from the whole frame."""
+    cr, mats = rt3.scene_stress(100000, 43)
+    W, H = 1920, 1080
+    cam = rt3.Camera().look_at(W, H, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
+    case = dict(spheres=cr, smats=mats, cam=cam.c, params=dict(width=W, height=H, spp=4, max_depth=50, seed=9, flags=1))
+    rows = dict(tile_rows=1, tile_index=200, tile_count=540)                   # rows 200 and 740
+    want, casts = oracle_render(case, threads=16, **rows)
+    got = hip_render(renderer, case, **rows)
+    assert_same(got, want, "config 4 depth 50 rows")
+    assert renderer.stats().ray_casts == casts
+    whole = hip_render(renderer, case, upload=False)
+    assert_same(np.stack([whole[200], whole[740]]), want, "config 4 depth 50, whole frame")
 
 
 def test_stress_scene_small_whole_image(rt3, renderer):
@@ -131,6 +168,14 @@ def test_config5_cornell_triangles_multi_tile(rt3, renderer):
     whole = hip_render(renderer, case)
     want, _ = oracle_render(case, threads=16, tile_rows=1, tile_index=200, tile_count=512)     # rows 200 and 712
     assert_same(np.stack([whole[200], whole[712]]), want, "config 5 rows")
+    # the config's own depth (50): paths end at the emitter, through the open front or after 50 casts (7 casts per sample on average)
+    deep = dict(case, params=dict(case["params"], max_depth=50, seed=6))
+    rows = dict(tile_rows=1, tile_index=300, tile_count=512)                   # rows 300 and 812
+    want, casts = oracle_render(deep, threads=16, **rows)
+    assert_same(hip_render(renderer, deep, upload=False, **rows), want, "config 5 depth 50 rows")
+    assert renderer.stats().ray_casts == casts and casts > 5 * 2 * 2 * 1024
+    whole = hip_render(renderer, deep, upload=False)
+    assert_same(np.stack([whole[300], whole[812]]), want, "config 5 depth 50, whole frame")
     small_f, small_v, small_m = rt3.scene_cornell(12)                        # 1658 faces: 7 LDS tiles
     cam = rt3.Camera().update(96, 96, 2.0, 2.0, 2.0)
     case = dict(faces=small_f, verts=small_v, fmats=small_m, cam=cam.c,

@@ -66,6 +66,25 @@ def test_object_errors_are_fatal(rt3, tmp_path):
         rt3.create_object(str(bad), (0, 0, 0), 1.0, (1, 1, 1))
 
 
+@pytest.mark.parametrize("body", [
+    "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n",            # a face names a vertex the file does not hold
+    "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 -3\n",           # negative index
+    "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 1e20\n",         # not a 32-bit index
+    "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 nan\n",
+])
+def test_malformed_object_indices_are_fatal_not_out_of_bounds(rt3, tmp_path, body):
+    """The reference indexes through Tools::Array and casts blindly (Object.cpp:157-170, :188-194); this port checks
+    the rebased indices against the vertex count before it reads through raw pointers."""
+    path = tmp_path / "bad_index.obj"
+    path.write_text(body)
+    try:
+        e = rt3.create_object(str(path), (0, 0, 0), 1.0, (1, 1, 1))
+    except rt3.Fatal:
+        return                                              # "nan" does not parse as a float with every libc: also fatal
+    with pytest.raises(rt3.Fatal):
+        rt3.pre_render_entity(e)
+
+
 def test_teddy_matches_oracle(rt3, oracle):
     if not os.path.exists(TEDDY):
         pytest.skip("/root/reference not present (GPU box)")

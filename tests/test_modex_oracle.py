@@ -39,6 +39,54 @@ def test_mode_x_reduces_to_mode_r_up_to_edge_pixels(oracle):
     assert (out != ref).sum() < 0.005 * w * h
 
 
+def test_reference_primary_flag_makes_mode_x_equal_mode_r_and_the_reference_hash(oracle):
+    """SURVEY.md section 0, consequence 1(i) / T7: Mode X with spp 1, depth 1, flat faces, t_min 0, no gamma and
+    RT3_FLAG_REFERENCE_PRIMARY (unnormalised primary ray, the reference's literal plane formula, SequentialRenderer.cpp:70,293)
+    IS Mode R — every pixel — and so reproduces the PPM SHA-256 recorded from the reference itself."""
+    import json
+    import os
+    from cases import GOLDEN
+    pins = json.load(open(os.path.join(GOLDEN, "reference_pins.json")))
+    faces, verts = load_builtin_scene()
+    w, h = 400, 225
+    cam = rt3.main_camera(w, h)
+    case = dict(faces=faces.view(rt3.GFACE), verts=verts, fmats=None, cam=cam.c,
+                params=dict(width=w, height=h, spp=1, max_depth=1, seed=1, flags=oracle.FLAG_REFERENCE_PRIMARY, t_min=0.0))
+    out, casts = oracle_render(case)
+    assert casts == w * h
+    ref = oracle.render_mode_r(faces, verts, oracle.camera_update(w, h), w, h)        # all rows (row h-1 as the GLSL twin)
+    assert np.array_equal(out, ref)
+    ref_like = out.copy()
+    ref_like[h - 1] = 0                                        # the reference's CPU loop never writes row H-1 (:286)
+    assert oracle.sha256(oracle.ppm_bytes(ref_like)) == pins["ppm_sha256"]["400x225"]
+    # the seed, the sample count law and the depth do not matter for flat faces: still Mode R with depth 7
+    out7, _ = oracle_render(case, max_depth=7, seed=99)
+    assert np.array_equal(out7, ref)
+
+
+def test_progressive_accumulation_is_partition_invariant(oracle):
+    """reduce_v1.glsl intent: samples are summed in sample order, so rendering [0, spp) in any consecutive pieces — carrying
+    the per-pixel sums (and sums of squares) from call to call — gives the frame, the sums and the ray casts of one call."""
+    case = mode_x_cases()["weekend_96x54x4_d50_lens"]
+    params = dict(case["params"], width=48, height=27, spp=16, flags=1 | oracle.FLAG_VARIANCE)
+    cam = oracle.copy_camera(case["cam"])
+    kw = dict(spheres=case["spheres"], smats=np.ascontiguousarray(case["smats"]).view(oracle.MATERIAL))
+    p = oracle.make_params(**params)
+    whole, acc, sq, casts = oracle.render_path_range(cam, p, 0, 16, **kw)
+    plain, plain_casts = oracle_render(case, width=48, height=27, spp=16, flags=1)
+    assert np.array_equal(whole, plain) and casts == plain_casts           # the variance flag changes no pixel
+    acc2 = sq2 = None
+    total = 0
+    for begin, count in ((0, 5), (5, 1), (6, 10)):
+        img, acc2, sq2, c = oracle.render_path_range(cam, p, begin, count, acc2, sq2, **kw)
+        total += c
+    assert np.array_equal(img, whole) and total == casts
+    assert acc2.tobytes() == acc.tobytes() and sq2.tobytes() == sq.tobytes()
+    # a variance estimate from the two sums: non-negative up to rounding, zero where every sample saw the same radiance
+    mean, mean_sq = acc[..., :3] / 16.0, sq[..., :3] / 16.0
+    assert (mean_sq - mean * mean > -1e-4).all() and (mean_sq - mean * mean).max() > 1e-3
+
+
 def test_depth_one_lambertian_is_black_and_depth_grows_brightness():
     case = mode_x_cases()["three_spheres_64x36x16_d8"]
     d1, _ = oracle_render(case, max_depth=1, spp=4)
