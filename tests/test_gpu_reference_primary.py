@@ -73,8 +73,6 @@ def test_flag_with_materials_depth_and_samples_equals_the_oracle(rt3, renderer):
     want, casts = oracle_render(case, threads=16)
     got = hip_render(renderer, case)
     assert np.array_equal(got, want) and renderer.stats().ray_casts == casts
-    plain, _ = oracle_render(case, threads=16, flags=1 | 2)
-    assert not np.array_equal(plain, want)                  # the flag is not a no-op once samples are jittered
 
 
 def test_camera_off_the_origin_or_with_a_lens_takes_the_unfiltered_kernel(rt3, renderer):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of two builds on the config-4 and config-5 shapes (global gathers in the exact test):
-    python tools/ab_cfg.py libA.so libB.so"""
+    python tools/ab_cfg.py libA.so libB.so [libC.so ...]      (every library against the first)"""
 import ctypes as C
 import importlib
 import os
@@ -16,7 +16,7 @@ rt3 = importlib.import_module("raytracer-3_amd")
 
 
 def main():
-    paths = sys.argv[1:3]
+    paths = sys.argv[1:]
     libs = []
     for path in paths:
         L = C.CDLL(os.path.abspath(path))
@@ -52,7 +52,31 @@ def main():
                 else:
                     outs.append(out)
         med = [statistics.median(t) for t in times]
-        print("%-40s A %.2f ms  B %.2f ms  B/A %.4f  identical %s" % (name, med[0], med[1], med[1] / med[0], np.array_equal(outs[0], outs[1])))
+        for i in range(1, len(libs)):
+            print("%-36s A %.2f ms  %-28s %.2f ms  x%.4f  identical %s" % (name, med[0], os.path.basename(paths[i]), med[i], med[i] / med[0],
+                                                                          np.array_equal(outs[0], outs[i])), flush=True)
+    # Mode R, built-in scene at 1080p (the fixture with a reference CPU time behind it)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "builtin_scene.npz"))
+    faces, verts = np.ascontiguousarray(z["faces"].view(rt3.GFACE).reshape(-1)), np.ascontiguousarray(z["verts"])
+    cam = rt3.main_camera(1920, 1080)
+    outs, times = [], [[] for _ in libs]
+    for r in range(6):
+        for i, (L, ctx) in enumerate(libs):
+            if r == 0:
+                L.rt3_set_spheres(ctx, None, None, 0)
+                L.rt3_set_mesh(ctx, faces.ctypes.data_as(C.c_void_p), C.c_uint32(len(faces)), verts.ctypes.data_as(C.c_void_p), C.c_uint32(len(verts)), None)
+            out = np.zeros((1080, 1920), np.uint32)
+            assert L.rt3_render(ctx, C.byref(cam.c), C.c_uint32(1920), C.c_uint32(1080), out.ctypes.data_as(C.c_void_p)) == 0, L.rt3_last_error(ctx)
+            st = rt3.rt3_stats()
+            L.rt3_get_stats(ctx, C.byref(st))
+            if r > 0:
+                times[i].append(st.trace_ms)
+            else:
+                outs.append(out)
+    med = [statistics.median(t) for t in times]
+    for i in range(1, len(libs)):
+        print("%-36s A %.3f ms  %-28s %.3f ms  x%.4f  identical %s" % ("mode R built-in 1920x1080", med[0], os.path.basename(paths[i]), med[i], med[i] / med[0],
+                                                                      np.array_equal(outs[0], outs[i])), flush=True)
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@ import numpy as np  # noqa: E402
 
 rt3 = importlib.import_module("raytracer-3_amd")
 quick = "--quick" in sys.argv
+only = [a for a in sys.argv[1:] if a.isdigit()]                      # e.g. `4 5`: just those configs
 
 
 def run_path(r, name, cam, params, reps=1):
@@ -25,7 +26,11 @@ def run_path(r, name, cam, params, reps=1):
         st = r.stats()
         row = dict(config=name, samples=st.samples, ray_casts=st.ray_casts, prim_tests=st.prim_tests, kernel_ms=round(st.trace_ms, 3),
                    total_ms=round(st.total_ms, 3), wall_ms=round(wall * 1e3, 3), launches=st.launches,
-                   msamples_per_s=round(st.samples / st.total_ms / 1e3, 1), gtests_per_s=round(st.prim_tests / st.trace_ms / 1e6, 1))
+                   msamples_per_s=round(st.samples / st.total_ms / 1e3, 1), gtests_per_s=round(st.prim_tests / st.trace_ms / 1e6, 1),
+                   mfma=st.mfma_instructions, mfma_frac_of_2500TF=round(st.mfma_instructions * 32768.0 / (st.trace_ms * 1e-3) / 2.5e15, 4),
+                   exact_per_cast=round(st.exact_tests / max(1, st.ray_casts), 2),
+                   # MFMA work is per wave whatever the number of live lanes: tests the matrix cores evaluated / tests that were needed
+                   lane_efficiency=round(st.prim_tests / max(1.0, st.mfma_instructions / 8.0 * 32 * 64), 4))
         if best is None or row["total_ms"] < best["total_ms"]:
             best = row
     print(json.dumps(best), flush=True)
@@ -48,6 +53,8 @@ def main():
                               kernel_ms=round(st.trace_ms, 4), msamples_per_s=round(st.samples / st.trace_ms / 1e3, 1),
                               gtests_per_s=round(st.prim_tests / st.trace_ms / 1e6, 1))), flush=True)
     r.set_mesh(*empty_mesh)
+    if only:
+        return tiled_only(r)
     # config 1
     cr, mats = rt3.scene_three_spheres()
     r.set_spheres(cr, mats)
@@ -72,6 +79,22 @@ def main():
     cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
     spp5 = 4 if quick else 16
     run_path(r, "5: cornell 47k tris 1024x1024x%d d50 (of 2048 spp)" % spp5, cam, rt3.make_params(1024, 1024, spp=spp5, max_depth=50, flags=3))
+
+
+def tiled_only(r):
+    spp = int(os.environ.get("SPP", "16"))
+    if "4" in only:
+        cr, mats = rt3.scene_stress(100000, 43)
+        r.set_mesh(np.zeros(0, rt3.GFACE), np.zeros((0, 4), np.float32))
+        r.set_spheres(cr, mats)
+        cam = rt3.Camera().look_at(1920, 1080, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
+        run_path(r, "4: 100k spheres 1920x1080x%d d50" % spp, cam, rt3.make_params(1920, 1080, spp=spp, max_depth=50, flags=1))
+    if "5" in only:
+        faces, verts, fm = rt3.scene_cornell(64)
+        r.set_spheres(np.zeros((0, 4), np.float32), np.zeros(0, rt3.MATERIAL))
+        r.set_mesh(faces, verts, fm)
+        cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
+        run_path(r, "5: cornell 47k tris 1024x1024x%d d50" % spp, cam, rt3.make_params(1024, 1024, spp=spp, max_depth=50, flags=3))
 
 
 if __name__ == "__main__":
