@@ -7,13 +7,24 @@ dielectric), 1920x1080, 512 spp, depth 50, thin-lens camera, gamma 2.  One "step
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the same frame is sharded in interleaved rows
 (rt3_params.tile_*), every rank renders its rows, then ONE RCCL gather brings the packed RGBA8 rows to rank 0, which
-de-interleaves them on the device.  Total work is fixed, so scaling = "strong".
+puts them at their frame rows with one indexed copy.  Total work is fixed, so scaling = "strong".
+N = 1: the rows go through rt3_gather_rows (the C ABI's device-to-device gather), no collective.
 
-Prints one JSON line (rank 0) with the metric, a `roofline` object for the dominant kernel (k_trace_mfma: algorithmic f32
-FLOP against the f32 peak), the executed bf16 matrix work beside it, the HBM figure north_star asks for, and
-a `cpu_baseline` object (the CPU oracle timed on this host's cores on a bounded sample of the same workload).
+Prints one JSON line (rank 0).  Beside the driver's fields:
+  roofline         the dominant kernel (k_trace_mfma) against the bound it actually runs on: EXECUTED bf16 matrix FLOP
+                   (v_mfma_f32_32x32x16_bf16 instructions counted by the kernel itself x 32768) / kernel time measured
+                   live with HIP events on the launch stream, over the 2.5 PFLOP/s dense bf16 peak.  `live` names the
+                   fields measured in this run; `traffic` and `valu_issue` are hardware-counter figures that only
+                   rocprofv3 can collect — they are taken from the committed profile of this same command and carry
+                   its provenance, or are null when that profile was made from other kernel sources
+  algorithmic_equiv  SURVEY.md §8d's per-test figure (20 f32 FLOP per ray-sphere test) priced against the f32 peak — the
+                   work a scalar formulation would do; NOT a roofline fraction of this kernel (it exceeds 1)
+  cpu_baseline     the CPU oracle timed on this host's cores on a bounded sample of the same workload
+  extra_workloads  short runs of the other BASELINE.json configs and of the Mode-R fixture (the only workload with a
+                   reference CPU time behind it), each with its own executed-MFMA fraction
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -28,10 +39,24 @@ WIDTH, HEIGHT, SPP, DEPTH = 1920, 1080, 512, 50
 SCENE_SEED, RENDER_SEED = 42, 1
 TILE_ROWS = 1                        # single-row interleave: 1080 rows split exactly evenly over 2, 4 or 8 ranks
 FLOP_PER_SPHERE_TEST = 20.0          # 3 sub, 6 (b), 7 (c), 4 (D); hit-only sqrt/divide excluded
-FLOP_PER_TRI_TEST = 17.0             # conservative: every triangle test counted at its early-out cost
+FLOP_PER_MFMA = 32768.0              # v_mfma_f32_32x32x16_bf16: 32 x 32 x 16 multiply-adds
 PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X_MICROARCH.md:41
 PEAK_HBM_GBS = 8000.0                # MI355X_MICROARCH.md:36
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense, MI355X_MICROARCH.md:43
+PMC_PROFILE = os.path.join("profiles", "r02_bench_pmc_k_trace.json")
+MODE_R_REFERENCE_CPU_S = 60.2        # SequentialRenderer (the reference's own CPU backend), built-in scene at 1920x1080:
+                                     # SURVEY.md §6/§8d, measured by the survey on an 8-vCPU Xeon 2.1 GHz, 1 thread, -O2
+
+
+def source_fingerprint():
+    """SHA-256 (first 16 hex digits) of the kernel sources: a committed profile only speaks for the build it was made from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer-3_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_cores():
@@ -56,7 +81,6 @@ def cpu_baseline(rt3, cr, mats, cam, budget_s):
     """Times the CPU oracle (kind 'port': the reference has no Mode-X renderer and cannot be built here) on a
     bounded sample of the same workload: same scene / camera / depth / spp law, reduced frame and spp."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_lib as O
     cores = host_cores()
     ocam = O.Camera()
@@ -94,6 +118,103 @@ def cpu_baseline(rt3, cr, mats, cam, budget_s):
             "value_1thread": round(rate_1, 4)}
 
 
+def counters_from_profile(fingerprint):
+    """HBM traffic per k_trace launch and vector-ALU issue utilisation from the committed rocprofv3 --pmc passes of THIS command
+    (tools/profile_final.sh).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is; both
+    count KiB.  Returns (traffic_bytes, traffic_source, valu_issue dict) — Nones when there is no profile or it is stale."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
+    except (OSError, ValueError):
+        return None, "no committed profile (%s)" % PMC_PROFILE, None
+    made_from = pmc.get("_source_fingerprint")
+    if made_from != fingerprint:
+        return None, "%s was collected on kernel sources %s, this build is %s: stale, not reported" % (PMC_PROFILE, made_from, fingerprint), None
+    src = "%s (separate rocprofv3 --pmc passes of `python3 bench.py`, kernel sources %s)" % (PMC_PROFILE, made_from)
+    try:
+        traffic = int((2.0 * pmc["FETCH_SIZE"]["sum_over_dispatches"] / pmc["FETCH_SIZE"]["dispatches"] +
+                       pmc["WRITE_SIZE"]["sum_over_dispatches"] / pmc["WRITE_SIZE"]["dispatches"]) * 1024)
+        busy = pmc["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0 / (pmc["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0)
+        valu = {"frac": round(busy, 3), "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] / pmc["SQ_INSTS_VALU"]["dispatches"]),
+                "source": src, "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x busy cycles): vector-ALU instruction issue, the resource "
+                                       "this kernel saturates beside the matrix pipe"}
+        return traffic, src, valu
+    except (KeyError, ZeroDivisionError):
+        return None, "%s lacks FETCH_SIZE / WRITE_SIZE" % PMC_PROFILE, None
+
+
+def executed(st, prims_per_cast):
+    """Executed-work figures of the last render on a context, from the kernel's own counters and its HIP-event time."""
+    k_ms = st.trace_ms
+    tf = st.mfma_instructions * FLOP_PER_MFMA / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    d = {"kernel_ms": round(k_ms, 3), "launches": st.launches, "ray_casts": int(st.ray_casts), "prim_tests": int(st.prim_tests),
+         "tests_per_s": round(st.prim_tests / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
+         "mfma_tflops": round(tf, 1), "mfma_frac_of_bf16_peak": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)}
+    if st.mfma_instructions:
+        # the matrix cores work per wave whatever the number of live lanes: tests needed / tests the issued MFMAs evaluated
+        d["lane_efficiency"] = round(st.prim_tests / (st.mfma_instructions / 8.0 * 32 * 64), 4)
+    if st.exact_tests:
+        d["exact_tests_per_cast"] = round(st.exact_tests / max(1, st.ray_casts), 2)
+    return d
+
+
+def extra_workloads(rt3, r, np):
+    """Short, driver-visible runs of the other workloads (kernel time = HIP events inside the C ABI; scene upload excluded)."""
+    out = []
+    empty_f, empty_v = np.zeros(0, rt3.GFACE), np.zeros((0, 4), np.float32)
+    no_sph = (np.zeros((0, 4), np.float32), np.zeros(0, rt3.MATERIAL))
+
+    def path(name, cam, params, kernel):
+        r.render_path(cam.c, params)                                     # warm-up: allocations, occupancy query
+        r.render_path(cam.c, params)
+        st = r.stats()
+        d = {"workload": name, "kernel": kernel, "samples": int(st.samples), "ms": round(st.total_ms, 3),
+             "msamples_per_s": round(st.samples / st.total_ms / 1e3, 2)}
+        d.update(executed(st, 0))
+        out.append(d)
+
+    # Mode R: the reference's own render (SequentialRenderer::render) of its built-in scene, the one workload with a reference CPU time
+    fixture = os.path.join(ROOT, "tests", "golden", "builtin_scene.npz")
+    if os.path.exists(fixture):
+        z = np.load(fixture)
+        faces = z["faces"].view(rt3.GFACE).reshape(-1)
+        r.set_mesh(faces, z["verts"])
+        r.set_spheres(*no_sph)
+        cam = rt3.main_camera(1920, 1080)
+        times = []
+        for _ in range(6):
+            r.render(cam)
+            times.append(r.stats().trace_ms)
+        ms = sorted(times[1:])[len(times[1:]) // 2]
+        npix, nf = 1920 * 1080, len(faces)
+        waves, blocks = -(-npix // 1024) * 16, -(-nf // 32)
+        tf = waves * blocks * 8 * FLOP_PER_MFMA / (ms * 1e-3) / 1e12
+        out.append({"workload": "Mode R: built-in scene of src/Main.cpp:280-283 (teddy.obj + 8x8 sphere, %d faces), 1920x1080, 1 ray per pixel" % nf,
+                    "kernel": "k_mode_r_mfma", "samples": npix, "ms": round(ms, 4), "msamples_per_s": round(npix / ms / 1e3, 1),
+                    "prim_tests": npix * nf, "tests_per_s": round(npix * nf / (ms * 1e-3), 1),
+                    "mfma_tflops": round(tf, 1), "mfma_frac_of_bf16_peak": round(tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "reference_cpu_s": MODE_R_REFERENCE_CPU_S, "speedup_vs_reference_cpu": round(MODE_R_REFERENCE_CPU_S / (ms * 1e-3), 0),
+                    "note": "reference_cpu_s: the reference's SequentialRenderer on this frame, 1 thread, measured by the survey (SURVEY.md §6); "
+                            "pixels equal the reference's PPM SHA-256 (tests/test_gpu_mode_r.py)"})
+        r.set_mesh(empty_f, empty_v)
+    # (config 3 runs the headline kernel on the headline scene: leaving it out keeps k_trace_mfma's rocprofv3 average = the headline launch)
+    # config 4: 100 000 spheres
+    cr, mats = rt3.scene_stress(100000, 43)
+    r.set_mesh(empty_f, empty_v)
+    r.set_spheres(cr, mats)
+    cam = rt3.Camera().look_at(1920, 1080, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
+    path("config 4: 100 000 spheres, 1920x1080, 16 of 256 spp, depth 50", cam,
+         rt3.make_params(1920, 1080, spp=16, max_depth=50, flags=rt3.FLAG_GAMMA2), "k_trace_mfma_tiled<spheres>")
+    # config 5: Cornell-style box, 47 106 triangles, emissive quad
+    faces, verts, fm = rt3.scene_cornell(64)
+    r.set_spheres(*no_sph)
+    r.set_mesh(faces, verts, fm)
+    cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
+    path("config 5: Cornell-style box, %d triangles, emissive quad, 1024x1024, 32 of 2048 spp, depth 50" % len(faces), cam,
+         rt3.make_params(1024, 1024, spp=32, max_depth=50, flags=rt3.FLAG_GAMMA2 | rt3.FLAG_BLACK_BACKGROUND), "k_trace_mfma_tiled<faces>")
+    r.set_mesh(empty_f, empty_v)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +225,7 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP)
     ap.add_argument("--depth", type=int, default=DEPTH)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads runs")
     ap.add_argument("--save-ppm", default="", help="rank 0 writes the last frame here")
     args = ap.parse_args()
 
@@ -136,13 +258,13 @@ def main():
                               lens_radius=0.05, tile_rows=TILE_ROWS, tile_index=i, tile_count=world) for i in range(world)]
     my = params[rank]
     shard = importlib.import_module("raytracer-3_amd.shard")
-    g = shard.FrameGatherer(rt3, params, rank, dev, force_collective=use_dist and world == 1)
+    g = shard.FrameGatherer(rt3, params, rank, dev, force_collective=use_dist and world == 1, renderer=r)
     tile = g.tile
     stream = torch.cuda.current_stream()
 
     def step():
         r.render_path_device(cam.c, my, tile.data_ptr(), stream.cuda_stream)
-        g.gather()                                                       # N>1: ONE RCCL gather over xGMI (8.3 MB / N per peer)
+        g.gather(stream.cuda_stream)           # N>1: ONE RCCL gather over xGMI (8.3 MB / N per peer); N=1: rt3_gather_rows on the same stream
 
     def sync():
         if use_dist:
@@ -152,7 +274,6 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    trace_ms, tests, casts = 0.0, 0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -172,22 +293,28 @@ def main():
         samples = W * H * args.spp
         ms_per_step = elapsed / args.steps * 1e3
         value = samples / (elapsed / args.steps) / 1e6
-        # roofline of the dominant kernel (k_trace) on THIS rank: algorithmic FLOP per launch / HIP-event duration
-        flop = st.prim_tests * FLOP_PER_SPHERE_TEST
-        k_ms = trace_ms / max(1, launches)
-        achieved = flop / max(1, launches) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        # algorithmic HBM bytes of the same launch: one 12-B radiance record per sample + the scene once per block
-        hbm_bytes = st.samples * 12.0 / max(1, launches)
-        # HBM traffic of one k_trace launch from the committed PMC passes of this same command (FETCH_SIZE is doubled as
-        # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is; both are in KiB); null if no profile is present
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench_pmc_k_trace.json")))
-            if world == 1 and (W, H, args.spp, args.depth) == (WIDTH, HEIGHT, SPP, DEPTH):
-                traffic = int((2.0 * pmc["FETCH_SIZE"]["sum_over_dispatches"] / pmc["FETCH_SIZE"]["dispatches"] +
-                               pmc["WRITE_SIZE"]["sum_over_dispatches"] / pmc["WRITE_SIZE"]["dispatches"]) * 1024)
-        except (OSError, KeyError, ValueError):
-            pass
+        n_launch = max(1, launches)
+        k_ms = trace_ms / n_launch                                       # average duration of one k_trace launch on THIS rank (HIP events)
+        mfma_tf = st.mfma_instructions * FLOP_PER_MFMA / n_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        alg_tf = st.prim_tests * FLOP_PER_SPHERE_TEST / n_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        hbm_bytes = st.samples * 12.0 / n_launch                         # algorithmic HBM bytes per launch: one 12-B radiance record per sample
+        fingerprint = source_fingerprint()
+        full_workload = world == 1 and (W, H, args.spp, args.depth) == (WIDTH, HEIGHT, SPP, DEPTH)
+        traffic, traffic_source, valu = counters_from_profile(fingerprint) if full_workload else (None, "not the profiled workload", None)
+        if st.mfma_instructions:
+            roofline = {"bound": "mfma", "kernel": "k_trace_mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(mfma_tf / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                        "kernel_ms": round(k_ms, 3), "launches_per_step": launches, "mfma_instructions_per_launch": int(st.mfma_instructions / n_launch),
+                        "live": ["achieved", "frac", "kernel_ms", "mfma_instructions_per_launch (counted by the kernel)"],
+                        "valu_issue": valu, "kernel_sources": fingerprint,
+                        "note": "EXECUTED work of the dominant kernel: v_mfma_f32_32x32x16_bf16 wave-instructions x 32768 FLOP / kernel time (HIP "
+                                "events on the launch stream) over the dense bf16 peak.  The kernel evaluates the discriminant of every (ray, sphere) "
+                                "pair as a bf16x3-split contraction on the matrix cores (DESIGN.md 5.2b); beside the matrix pipe it keeps the vector "
+                                "ALU issuing (valu_issue).  The sustained clock under this load is ~2.0-2.1 GHz of the 2.4 GHz the peak assumes"}
+        else:
+            roofline = {"bound": "mfma", "kernel": "k_trace (vector-ALU scan, RT3_NO_MFMA / RT3_BRUTE)", "achieved": 0.0, "peak": PEAK_BF16_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": 0.0, "traffic": None, "traffic_source": "A/B build, not profiled", "kernel_ms": round(k_ms, 3),
+                        "launches_per_step": launches, "live": ["kernel_ms"], "note": "no matrix instructions issued by this kernel selection"}
         out = {
             "metric": "Msamples/sec (pixels x spp) at %dx%dx%dspp" % (W, H, args.spp),
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,39 +322,22 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "In-One-Weekend final random-spheres scene, %d spheres (scene seed %d), %dx%d, %d spp, "
                                    "depth %d, thin lens, gamma 2" % (len(cr), SCENE_SEED, W, H, args.spp, args.depth),
-                       "sharding": "interleaved %d-row blocks over %d GPU(s), RCCL gather to rank 0" % (TILE_ROWS, world)},
+                       "sharding": ("interleaved %d-row blocks over %d GPU(s), RCCL gather to rank 0" % (TILE_ROWS, world)) if use_dist else
+                                   "one GPU, rows through rt3_gather_rows (device-to-device)"},
             "ray_casts": int(agg[1].item()), "prim_tests": int(agg[0].item()),
             "tests_per_s": round(agg[0].item() / (elapsed / args.steps), 1),
-            "roofline": {"bound": "mfma" if st.mfma_instructions else "valu",
-                         "kernel": "k_trace_mfma" if st.mfma_instructions else "k_trace<false,true,true>",
-                         "achieved": round(achieved, 3), "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
-                         "flop_per_test": FLOP_PER_SPHERE_TEST, "kernel_ms": round(k_ms, 3), "launches_per_step": launches,
-                         "note": "achieved = ALGORITHMIC 20 FLOP per ray-sphere test (SURVEY.md 8d) x tests / kernel time; peak = 157.3 "
-                                 "TFLOP/s, the f32 peak of gfx950 (dense f32 MFMA == f32 vector ALU).  The algorithmic work is f32; the "
-                                 "kernel executes its conservative candidate filter as bf16 MFMAs on 3-way split operands (see "
-                                 "roofline_mfma_bf16) with ONE vector instruction per test and the exact f32 test only on survivors, "
-                                 "which is how frac can exceed 1; what limits the kernel is vector-ALU instruction issue (valu_issue)"},
-            "roofline_mfma_bf16": {"bound": "mfma", "achieved": round(st.mfma_instructions * 32768.0 / max(1, launches) / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
-                                   "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(st.mfma_instructions * 32768.0 / max(1, launches) / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if k_ms > 0 else 0.0,
-                                   "note": "EXECUTED matrix work: v_mfma_f32_32x32x16_bf16 instructions x 32768 FLOP / kernel time vs the dense bf16 peak; "
-                                           "the vector ALU turns each result's sign into a candidate bit (1 instruction per pair) beside it"},
-            "roofline_hbm": {"bound": "hbm", "achieved": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else 0.0,
-                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5) if k_ms > 0 else 0.0,
-                             "traffic": traffic,
-                             "note": "algorithmic bytes = 12 B radiance record per sample; the 7.7 KB scene streams through the scalar "
-                                     "cache; traffic = PMC bytes per launch (profiles/), source of truth for re-reads"},
+            "roofline": roofline,
+            "algorithmic_equiv": {"flop_per_test": FLOP_PER_SPHERE_TEST, "tests_per_launch": int(st.prim_tests / n_launch), "tflops": round(alg_tf, 2),
+                                  "f32_peak_tflops": PEAK_FP32_VALU_TFLOPS, "ratio_to_f32_peak": round(alg_tf / PEAK_FP32_VALU_TFLOPS, 4),
+                                  "note": "SURVEY.md 8d's ALGORITHMIC work (20 f32 FLOP per ray-sphere test, tests = ray casts x spheres) per kernel "
+                                          "second, beside the f32 peak it would be priced against if it ran as scalar f32 code.  It is not executed in "
+                                          "that form, so this is an equivalence figure, not a roofline fraction"},
+            "hbm": {"algorithmic_bytes_per_launch": int(hbm_bytes), "achieved_gbs": round(hbm_bytes / (k_ms * 1e-3) / 1e9, 2) if k_ms > 0 else 0.0,
+                    "peak_gbs": PEAK_HBM_GBS, "frac": round(hbm_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5) if k_ms > 0 else 0.0,
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "note": "the figure north_star asks for: 12 B radiance record per sample; the 7.7 KB scene streams through LDS; "
+                            "a high fraction here would mean lost reuse, not success"},
         }
-        try:                                                     # vector-ALU issue utilisation of the same kernel, from the committed PMC pass
-            busy = pmc["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0 / (pmc["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0)
-            if traffic is not None:
-                out["valu_issue"] = {"frac": round(busy, 3), "valu_instructions": int(pmc["SQ_INSTS_VALU"]["sum_over_dispatches"]),
-                                     "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x busy cycles), profiles/r01_final_bench_pmc_k_trace.json: "
-                                             "the resource the kernel saturates"}
-        except (NameError, KeyError, ZeroDivisionError):
-            pass
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(rt3, cr, mats, cam, args.cpu_seconds)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
@@ -235,6 +345,8 @@ def main():
             f = rt3.Frame(W, H)
             f.data[:] = g.frame.cpu().numpy().view(np.uint32)
             f.to_ppm(args.save_ppm)
+        if world == 1 and full_workload and not args.no_extra:
+            out["extra_workloads"] = extra_workloads(rt3, r, np)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

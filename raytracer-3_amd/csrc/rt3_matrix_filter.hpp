@@ -421,6 +421,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
                 __syncthreads();                                                // every wave is done with the previous tile
                 for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = frags[(size_t)b0 * 256 + k];
                 __syncthreads();
+                if (live == 0ull) continue;                                     // a wave without rays (the tail of a launch) only keeps the barriers
                 const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
                 push_and_test(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
                 mfmas += nb * 8ull;

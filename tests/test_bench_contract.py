@@ -47,6 +47,11 @@ def test_bench_line_has_every_field_of_the_contract():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.0 < r["frac"] <= 1.0                                  # a roofline fraction: executed work over the peak of the unit that does it
+    assert r["peak"] == 2500.0 and "achieved" in r["live"] and "traffic_source" in r
+    assert r["traffic"] is None                                    # not the profiled workload (8 spp): counters are never guessed
+    a = d["algorithmic_equiv"]
+    assert a["flop_per_test"] == 20.0 and abs(a["tflops"] - d["prim_tests"] * 20.0 / (r["kernel_ms"] * 1e-3) / 1e12) / a["tflops"] < 0.02
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

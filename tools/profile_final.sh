@@ -4,6 +4,7 @@
 # rocprofv3 gets `python3 bench.py ...` directly after `--`; counters are collected in their own passes (no trace domains).
 export TMPDIR=/tmp
 out=gpurun_out/final
+export RT3_PROFILE_TAG=${RT3_PROFILE_TAG:-r02}
 rm -rf $out && mkdir -p $out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py > $out/bench_stdout.log 2>$out/bench_stderr.log || exit 1
 echo "trace pass done"
@@ -14,7 +15,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
            "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_VALU_MFMA_COEXEC_CYCLES"; do
     i=$((i+1))
-    timeout -k 10 150 rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; exit 1; }
+    timeout -k 10 150 rocprofv3 --pmc $set --output-format csv -d $out/pmc$i -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extra > $out/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $out/pmc$i.log; exit 1; }
     echo "pmc pass $i done"
 done
 python3 - <<'PY'
@@ -29,7 +30,7 @@ for f in sorted(glob.glob("gpurun_out/final/pmc*/*/*_counter_collection.csv")):
     for k, (v, d) in per.items():
         agg[k] = {"sum_over_dispatches": v, "dispatches": len(d)}
 json.dump(agg, open("gpurun_out/final/pmc_k_trace.json", "w"), indent=1)
-print(json.dumps({k: v["sum_over_dispatches"] for k, v in agg.items()}))
+print(json.dumps({k: v["sum_over_dispatches"] for k, v in agg.items() if isinstance(v, dict)}))
 PY
 head -5 $out/kernel_stats.csv
 cat $out/bench_line.json | cut -c1-400
