@@ -270,7 +270,7 @@ rt3_ctx* rt3_create(int device_id) {
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
         (e = hipStreamCreate(&ctx->stream)) != hipSuccess || (e = hipEventCreate(&ctx->ev_begin)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev_end)) != hipSuccess ||
-        (e = hipMalloc((void**)&ctx->d_work, 64)) != hipSuccess || (e = hipMalloc((void**)&ctx->d_casts, 64)) != hipSuccess) {
+        (e = hipMalloc((void**)&ctx->d_work, 64)) != hipSuccess || (e = hipMalloc((void**)&ctx->d_casts, 128)) != hipSuccess) {
         g_create_error = std::string("rt3_create: ") + hipGetErrorString(e);
         delete ctx;
         return nullptr;
@@ -645,9 +645,10 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     per_cu = std::min(per_cu, 8);
 
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
-    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 64, stream));
+    RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 128, stream));
 #ifdef RT3_PROFILE
     RT3_HIP(hipMemsetAsync(ctx->d_casts + 6, 0xFF, 8, stream));
+    RT3_HIP(hipMemsetAsync(ctx->d_casts + 8, 0xFF, 16, stream));       // [8] first wave start, [9] first time a wave found the queue empty
 #endif
     for (uint32_t s0 = sample_begin; s0 < sample_begin + sample_count; s0 += batch) {
         const uint32_t ns = std::min(batch, sample_begin + sample_count - s0);
@@ -810,13 +811,16 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
     out->n_spheres = ctx->n_sph;
     out->n_faces = ctx->n_faces;
     if (ctx->last_was_path) {
-        unsigned long long counters[8] = { 0 };
-        RT3_HIP(hipMemcpy(counters, ctx->d_casts, 64, hipMemcpyDeviceToHost));
+        unsigned long long counters[16] = { 0 };
+        RT3_HIP(hipMemcpy(counters, ctx->d_casts, 128, hipMemcpyDeviceToHost));
 #ifdef RT3_PROFILE
         fprintf(stderr, "[rt3 profile] wave iterations %llu, flush iterations/wave-iter %.2f, candidates/ray %.2f, live lanes/wave-iter %.1f, "
                         "fresh paths/wave-iter %.1f\n", counters[4], (double)counters[2] / (double)counters[4],
                 (double)counters[3] / (double)counters[0], (double)counters[0] / (double)counters[4], (double)counters[5] / (double)counters[4]);
         fprintf(stderr, "[rt3 profile] first wave ended %.1f us before the last one\n", (double)(counters[7] - counters[6]) / 100.0);
+        fprintf(stderr, "[rt3 profile] timeline from the first wave's start (us): last wave start %.1f, queue first seen empty %.1f, last seen empty %.1f, "
+                        "first wave end %.1f, last wave end %.1f\n", (double)(counters[11] - counters[8]) / 100.0, (double)(counters[9] - counters[8]) / 100.0,
+                (double)(counters[10] - counters[8]) / 100.0, (double)(counters[6] - counters[8]) / 100.0, (double)(counters[7] - counters[8]) / 100.0);
 #endif
         out->ray_casts = counters[0];
         out->prim_tests = counters[0] * ((uint64_t)ctx->n_sph + ctx->n_faces);

@@ -319,10 +319,18 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     unsigned long long casts = 0, iters = 0;
 #ifdef RT3_PROFILE
     unsigned long long prof_flush_iters = 0, prof_cands = 0, prof_refills = 0;
+    bool prof_dry_seen = false;
+    if (lane == 0) { const unsigned long long t0 = wall_clock64(); atomicMin(A.cast_counter + 8, t0); atomicMax(A.cast_counter + 11, t0); }
 #endif
 
     for (;;) {
         refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
+#ifdef RT3_PROFILE
+        if (exhausted && !prof_dry_seen) {
+            prof_dry_seen = true;
+            if (lane == 0) { const unsigned long long t = wall_clock64(); atomicMin(A.cast_counter + 9, t); atomicMax(A.cast_counter + 10, t); }
+        }
+#endif
         const unsigned long long live = __ballot(alive);
         if (live == 0ull) break;
         casts += (unsigned long long)__popcll(live);
