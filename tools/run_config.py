@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Renders one BASELINE.json config shape once (for profiling under rocprofv3): python tools/run_config.py 4|5 [spp]"""
+"""Renders one BASELINE.json config shape (4, 5) or the Mode-R fixture (r) once, for profiling under rocprofv3:
+    python tools/run_config.py 4|5|r [spp]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -7,6 +8,16 @@ rt3 = importlib.import_module("raytracer-3_amd")
 which = sys.argv[1] if len(sys.argv) > 1 else "4"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 r = rt3.HipRenderer()
+if which == "r":
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "builtin_scene.npz"))
+    r.set_mesh(z["faces"].view(rt3.GFACE).reshape(-1), z["verts"])
+    r.set_spheres(np.zeros((0, 4), np.float32), np.zeros(0, rt3.MATERIAL))
+    cam = rt3.main_camera(1920, 1080)
+    for _ in range(4):
+        r.render(cam)
+    st = r.stats()
+    print("mode R 1920x1080: kernel %.4f ms" % st.trace_ms)
+    sys.exit(0)
 if which == "4":
     cr, mats = rt3.scene_stress(100000, 43)
     r.set_spheres(cr, mats)
