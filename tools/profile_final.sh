@@ -29,6 +29,10 @@ for f in sorted(glob.glob("gpurun_out/final/pmc*/*/*_counter_collection.csv")):
             per[r["Counter_Name"]][1].add(r["Dispatch_Id"])
     for k, (v, d) in per.items():
         agg[k] = {"sum_over_dispatches": v, "dispatches": len(d)}
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", "bench.py"); B = importlib.util.module_from_spec(spec); spec.loader.exec_module(B)
+agg["_source_fingerprint"] = B.source_fingerprint()                 # bench.py reports these counters only for the sources they were collected on
+agg["_command"] = "rocprofv3 --pmc <set> -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extra (one pass per counter set); kernels matching k_trace"
 json.dump(agg, open("gpurun_out/final/pmc_k_trace.json", "w"), indent=1)
 print(json.dumps({k: v["sum_over_dispatches"] for k, v in agg.items() if isinstance(v, dict)}))
 PY
