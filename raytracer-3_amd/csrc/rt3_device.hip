@@ -814,13 +814,21 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
         unsigned long long counters[16] = { 0 };
         RT3_HIP(hipMemcpy(counters, ctx->d_casts, 128, hipMemcpyDeviceToHost));
 #ifdef RT3_PROFILE
+        if (counters[13] == 0)
         fprintf(stderr, "[rt3 profile] wave iterations %llu, flush iterations/wave-iter %.2f, candidates/ray %.2f, live lanes/wave-iter %.1f, "
                         "fresh paths/wave-iter %.1f\n", counters[4], (double)counters[2] / (double)counters[4],
                 (double)counters[3] / (double)counters[0], (double)counters[0] / (double)counters[4], (double)counters[5] / (double)counters[4]);
+        if (counters[13] != 0) {                                     // tiled kernel: where its waves spend their time
+            const double all = (double)(counters[12] + counters[13] + counters[14] + counters[15] + counters[4]);
+            fprintf(stderr, "[rt3 profile] tiled kernel, share of wave time: barriers + tile fill %.1f %%, scan %.1f %%, push %.1f %%, exact tests %.1f %%, "
+                            "refill / operands / shade %.1f %%\n", 100.0 * counters[12] / all, 100.0 * counters[13] / all, 100.0 * counters[14] / all,
+                    100.0 * counters[15] / all, 100.0 * counters[4] / all);
+        } else {
         fprintf(stderr, "[rt3 profile] first wave ended %.1f us before the last one\n", (double)(counters[7] - counters[6]) / 100.0);
         fprintf(stderr, "[rt3 profile] timeline from the first wave's start (us): last wave start %.1f, queue first seen empty %.1f, last seen empty %.1f, "
                         "first wave end %.1f, last wave end %.1f\n", (double)(counters[11] - counters[8]) / 100.0, (double)(counters[9] - counters[8]) / 100.0,
                 (double)(counters[10] - counters[8]) / 100.0, (double)(counters[6] - counters[8]) / 100.0, (double)(counters[7] - counters[8]) / 100.0);
+        }
 #endif
         out->ray_casts = counters[0];
         out->prim_tests = counters[0] * ((uint64_t)ctx->n_sph + ctx->n_faces);

@@ -228,12 +228,18 @@ __device__ __forceinline__ void mfma_flush_prefetch(uint32_t nz, uint32_t n_bloc
 // A ray has few candidates but they cluster (a ray skimming a tessellated wall meets dozens of bounding spheres in one tile while its
 // 63 neighbours meet none), so a loop in which every lane walks its OWN candidates runs at the pace of the unluckiest lane: 5.5 trips per
 // 512-row tile on the 47k-face scene for 0.33 candidates per lane.  Instead each lane pushes its candidates (ballot + prefix count)
-// into a wave-private list in LDS; as soon as 64 pairs are there, all 64 lanes run ONE exact test each — lane k takes pair k, fetches the
-// ray of the owning lane with ds_bpermute and the primitive from global memory — and a hit is folded into the owning ray's record by
+// into a wave-private list in LDS, and in a TEST PHASE all 64 lanes run one exact test each — lane k takes pair k, fetches the ray of the
+// owning lane with ds_bpermute and the primitive from global memory — and a hit is folded into the owning ray's record by
 // one 64-bit ds_min: key = (t bits, sphere?, primitive index, sign of t), so the minimum IS the sequential loops' answer (nearest t;
 // on equal t faces before spheres, then the lower index) whatever order the pairs are tested in.  t >= 0 always (t_min >= 0 is checked
 // by the host), so its bit pattern with the sign cleared orders like the number; the sign of a -0.0 rides in the lowest bit.
-constexpr uint32_t kPairCap = 128;                                  // per wave: < 64 left over + one round of <= 64 new pairs
+// WHEN the tests run matters as much: a test phase is two dependent trips to L2 (2-3 us), and the 16 waves of a workgroup meet at two
+// barriers per tile — a wave that tests on its own, whenever its list happens to fill, makes the other 15 wait (with 21 pairs per tile
+// and wave on the 47k-face scene some wave did so at nearly every tile: the matrix pipe was 50 % busy there against 70 % on a scene
+// with few candidates).  So the workgroup tests TOGETHER: a wave that holds kPairTrigger pairs raises a flag in LDS, and at the next
+// tile every wave works off whatever it holds — between the tile's two barriers, while the loads that fill the tile are in flight.
+constexpr uint32_t kPairCap = 192;                                  // per wave: up to 127 waiting + one round of <= 64 new pairs
+constexpr uint32_t kPairTrigger = 48;                               // a wave holding this many asks the workgroup for a test phase
 constexpr uint32_t kPairLaneShift = 26;                             // pair = lane << 26 | primitive row (< 2^26)
 constexpr unsigned long long kKeyNone = 0x7F800000FFFFFFFFull;      // t = +inf: what a real hit (t < inf) always beats
 __device__ __forceinline__ unsigned long long hit_key(float t, uint32_t is_sphere, uint32_t idx) {
@@ -257,11 +263,26 @@ __device__ __forceinline__ LaneRay fetch_ray(const LaneRay& mine, uint32_t src) 
     r.literal = REF ? __shfl((int)mine.literal, s) != 0 : false;
     return r;
 }
-// Pushes this lane's candidates of the tile just scanned (rows b0*32 ..) and runs `test(pair, valid)` — ALL lanes call it, `valid`
-// says whether the lane holds a pair — every time 64 pairs are available.  n_pairs (wave-uniform) carries the remainder to the next tile.
+// Runs `test(pair, valid)` — ALL lanes call it, `valid` says whether the lane holds a pair — on everything the list holds.
 template <class Test>
-__device__ __forceinline__ void push_and_test(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
-                                              uint32_t& n_pairs, Test&& test) {
+__device__ __forceinline__ void test_all(uint32_t lane, const uint32_t* pairs, uint32_t& n_pairs, Test&& test) {
+    while (n_pairs >= 64u) {
+        n_pairs -= 64u;
+        test(pairs[n_pairs + lane], true);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (n_pairs != 0u) {
+        const bool valid = lane < n_pairs;
+        test(valid ? pairs[lane] : 0u, valid);
+        __builtin_amdgcn_wave_barrier();
+        n_pairs = 0u;
+    }
+}
+// Pushes this lane's candidates of the tile just scanned (rows row0 ..) into the wave's list; n_pairs (wave-uniform) is the fill.
+// Tests run at the workgroup's test phases (see the tiled kernels); only a list about to overflow is worked off on the spot.
+template <class Test>
+__device__ __forceinline__ void push_pairs(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
+                                           uint32_t& n_pairs, Test&& test) {
     CandIter it = { nz, 0u, 0u, n_blocks };
     for (;;) {
         uint32_t row = 0;
@@ -271,20 +292,11 @@ __device__ __forceinline__ void push_and_test(uint32_t nz, uint32_t n_blocks, co
         if (have) pairs[n_pairs + prefix_count(m)] = (lane << kPairLaneShift) | (row0 + row);
         n_pairs += (uint32_t)__popcll(m);
         __builtin_amdgcn_wave_barrier();                            // (LDS serves one wave's requests in order; this only pins the compiler)
-        if (n_pairs >= 64u) {
+        if (n_pairs > kPairCap - 64u) {
             n_pairs -= 64u;
             test(pairs[n_pairs + lane], true);
             __builtin_amdgcn_wave_barrier();
         }
-    }
-}
-template <class Test>
-__device__ __forceinline__ void test_leftover(uint32_t lane, const uint32_t* pairs, uint32_t& n_pairs, Test&& test) {
-    if (n_pairs != 0u) {
-        const bool valid = lane < n_pairs;
-        test(valid ? pairs[lane] : 0u, valid);
-        __builtin_amdgcn_wave_barrier();
-        n_pairs = 0u;
     }
 }
 
@@ -388,7 +400,20 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
 // workgroup move through the tiles together (two barriers per tile); candidates go through the pair list above, the exact tests
 // gather their records from global memory, all 64 lanes at a time.
 // REF: RT3_FLAG_REFERENCE_PRIMARY (camera at the origin, no lens: checked by the host).
-constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;
+constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4 + 16;
+// One tile of fragments through the workgroup: [barrier] loads -> `between()` -> LDS stores [barrier].  `between` is where a test phase
+// runs, its memory traffic overlapping the fill's.
+template <class Between>
+__device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict__ src, uint32_t n_vec, uint32_t tid, Between&& between) {
+    __syncthreads();                                                // every wave is done with the previous tile (and has posted its wish to test)
+    u32x4 v[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) v[i] = src[min(tid + i * kMB, n_vec - 1u)];       // unconditional: four loads in flight, no branches
+    between();
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) { const uint32_t k = tid + i * kMB; if (k < n_vec) s_frag[k] = v[i]; }
+    __syncthreads();
+}
 template <bool HAS_TRI, bool HAS_SPH, bool REF>
 __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     extern __shared__ u32x4 lds_dyn[];
@@ -396,9 +421,12 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);           // [16][kMB] candidate words
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kMB);   // [kMB] nearest hit of every lane's ray
     uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kMB);              // [16 waves][kPairCap]
+    uint32_t* s_flag = s_pairs + (kMB / 64) * kPairCap;                        // [2] "some wave wants a test phase at the next tile", by tile parity
     const uint32_t tid = threadIdx.x, lane = lane_id();
     uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
     unsigned long long* keys = s_key + (tid & ~63u);                           // this wave's 64 records
+    if (tid < 2) s_flag[tid] = 0u;                                             // (the first barrier of the loop below publishes it)
+    uint32_t parity = 0;                                                       // workgroup-uniform tile counter & 1
 
     Path P;
     P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
@@ -407,6 +435,12 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
     unsigned long long casts = 0, mfmas = 0, exact = 0;
+#ifdef RT3_PROFILE                                                              // wall-clock ticks (100 MHz) of this wave per phase
+    unsigned long long pt_fill = 0, pt_scan = 0, pt_push = 0, pt_test = 0, pt_rest = 0, pt_mark = wall_clock64();
+#define RT3_PHASE(acc) { const unsigned long long now_ = wall_clock64(); acc += now_ - pt_mark; pt_mark = now_; }
+#else
+#define RT3_PHASE(acc)
+#endif
 
     for (;;) {
         // (no ray stock here: a ray cast costs at least one tile scan, start_path is noise beside it, and the stock's 8 registers are needed)
@@ -424,17 +458,26 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
 
         auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& test) {
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
-            for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
+            for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16, parity ^= 1u) {
                 const uint32_t nb = min(16u, total_blocks - b0);
-                __syncthreads();                                                // every wave is done with the previous tile
-                for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = frags[(size_t)b0 * 256 + k];
-                __syncthreads();
+                RT3_PHASE(pt_rest)
+                fill_tile(s_frag, frags + (size_t)b0 * 256, nb * 256, tid, [&]() {
+                    RT3_PHASE(pt_fill)
+                    if (s_flag[parity] != 0u) test_all(lane, pairs, n_pairs, test);         // workgroup-uniform: a test phase for everybody
+                    RT3_PHASE(pt_test)
+                });
+                RT3_PHASE(pt_fill)
+                if (tid == 0) s_flag[parity] = 0u;                              // everybody has read it (second barrier); it is set again two barriers from now
                 if (live == 0ull) continue;                                     // a wave without rays (the tail of a launch) only keeps the barriers
                 const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-                push_and_test(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
+                RT3_PHASE(pt_scan)
+                push_pairs(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
+                if (n_pairs >= kPairTrigger) s_flag[parity ^ 1u] = 1u;
+                RT3_PHASE(pt_push)
                 mfmas += nb * 8ull;
             }
-            test_leftover(lane, pairs, n_pairs, test);
+            test_all(lane, pairs, n_pairs, test);                               // what is left at the end of the pass
+            RT3_PHASE(pt_test)
         };
         if (HAS_TRI) {
             auto test = [&](uint32_t pair, bool valid) {
@@ -443,9 +486,11 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
                 exact += (unsigned long long)__popcll(__ballot(valid));
                 if (!valid || j >= A.n_tri) return;
                 const float4* f = A.tri + (size_t)j * 4;
+                const float4 n = f[0], p1 = f[1], p2 = f[2], p3 = f[3];           // the whole 64-byte record at once: ONE trip to L2, not two
                 const float t_hi = __uint_as_float((uint32_t)(keys[src] >> 32));   // the ray's best t so far: farther faces need no edge tests
                 float t;
-                if (!face_hit<false>(f[0], f, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t_hi, r.literal, t)) return;
+                if (!face_t(n, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.literal, t) || !(t >= A.t_min && t <= t_hi)) return;
+                if (!face_inside(n, p1, p2, p3, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t)) return;
                 if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
             };
             pass(tri_frags, A.n_tri, test);
@@ -468,6 +513,14 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
         shade_lane<HAS_TRI, HAS_SPH, REF>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
     }
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, mfmas); atomicAdd(A.cast_counter + 2, exact); }
+#ifdef RT3_PROFILE
+    RT3_PHASE(pt_rest)
+    if (lane == 0) {
+        atomicAdd(A.cast_counter + 12, pt_fill); atomicAdd(A.cast_counter + 13, pt_scan); atomicAdd(A.cast_counter + 14, pt_push);
+        atomicAdd(A.cast_counter + 15, pt_test); atomicAdd(A.cast_counter + 4, pt_rest);
+    }
+#endif
+#undef RT3_PHASE
 }
 
 // Mode R through the matrix-core filter (camera at the origin, as k_mode_r_fast): one thread per pixel, 1024 pixels per
@@ -481,9 +534,12 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kMB);
     uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kMB);
+    uint32_t* s_flag = s_pairs + (kMB / 64) * kPairCap;
     const uint32_t tid = threadIdx.x, lane = lane_id();
     uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
     unsigned long long* keys = s_key + (tid & ~63u);
+    if (tid < 2) s_flag[tid] = 0u;
+    uint32_t parity = 0;
     const uint32_t pixel = blockIdx.x * kMB + tid;
     const bool valid_px = pixel < width * height;
     const uint32_t x = valid_px ? pixel % width : 0u, y = valid_px ? pixel / width : 0u;
@@ -505,21 +561,25 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
         const LaneRay r = fetch_ray<false>(ray, src);
         if (!valid || j >= n_faces) return;
         const float4* f = tri + (size_t)j * 4;
+        const float4 n = f[0], p1 = f[1], p2 = f[2], p3 = f[3];
         const float t_hi = __uint_as_float((uint32_t)(keys[src] >> 32));
         float t;
-        if (!face_hit<false>(f[0], f, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, 0.0f, t_hi, true, t)) return;     // :70-71: literal formula, t < 0 rejects
+        if (!face_t(n, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, true, t) || !(t >= 0.0f && t <= t_hi)) return;    // :70-71: literal formula, t < 0 rejects
+        if (!face_inside(n, p1, p2, p3, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t)) return;
         if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
     };
     const uint32_t total_blocks = (n_faces + 31u) / 32u;
-    for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
+    for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16, parity ^= 1u) {
         const uint32_t nb = min(16u, total_blocks - b0);
-        __syncthreads();
-        for (uint32_t k = tid; k < nb * 256; k += kMB) s_frag[k] = tri_frags[(size_t)b0 * 256 + k];
-        __syncthreads();
+        fill_tile(s_frag, tri_frags + (size_t)b0 * 256, nb * 256, tid, [&]() {
+            if (s_flag[parity] != 0u) test_all(lane, pairs, n_pairs, test);
+        });
+        if (tid == 0) s_flag[parity] = 0u;
         const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-        push_and_test(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
+        push_pairs(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
+        if (n_pairs >= kPairTrigger) s_flag[parity ^ 1u] = 1u;
     }
-    test_leftover(lane, pairs, n_pairs, test);
+    test_all(lane, pairs, n_pairs, test);
     __builtin_amdgcn_wave_barrier();
     if (!valid_px) return;
     uint32_t kind, min_i;
