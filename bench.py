@@ -145,13 +145,13 @@ def counters_from_profile(fingerprint):
 def executed(st, prims_per_cast):
     """Executed-work figures of the last render on a context, from the kernel's own counters and its HIP-event time."""
     k_ms = st.trace_ms
-    tf = st.mfma_instructions * FLOP_PER_MFMA / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    tf = st.mfma_instructions * float(st.mfma_flop_per_instruction) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     d = {"kernel_ms": round(k_ms, 3), "launches": st.launches, "ray_casts": int(st.ray_casts), "prim_tests": int(st.prim_tests),
          "tests_per_s": round(st.prim_tests / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
          "mfma_tflops": round(tf, 1), "mfma_frac_of_bf16_peak": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)}
     if st.mfma_instructions:
         # the matrix cores work per wave whatever the number of live lanes: tests needed / tests the issued MFMAs evaluated
-        d["lane_efficiency"] = round(st.prim_tests / (st.mfma_instructions / 8.0 * 32 * 64), 4)
+        d["lane_efficiency"] = round(st.prim_tests / (st.mfma_instructions * st.mfma_flop_per_instruction / 32768.0 / 8.0 * 32 * 64), 4)
     if st.exact_tests:
         d["exact_tests_per_cast"] = round(st.exact_tests / max(1, st.ray_casts), 2)
     return d
@@ -187,7 +187,7 @@ def extra_workloads(rt3, r, np):
         ms = sorted(times[1:])[len(times[1:]) // 2]
         npix, nf = 1920 * 1080, len(faces)
         waves, blocks = -(-npix // 1024) * 16, -(-nf // 32)
-        tf = waves * blocks * 8 * FLOP_PER_MFMA / (ms * 1e-3) / 1e12
+        tf = waves * blocks * 8 * FLOP_PER_MFMA / (ms * 1e-3) / 1e12           # 16 x 16x16x32 per row block and wave = 8 x 32768 FLOP
         out.append({"workload": "Mode R: built-in scene of src/Main.cpp:280-283 (teddy.obj + 8x8 sphere, %d faces), 1920x1080, 1 ray per pixel" % nf,
                     "kernel": "k_mode_r_mfma", "samples": npix, "ms": round(ms, 4), "msamples_per_s": round(npix / ms / 1e3, 1),
                     "prim_tests": npix * nf, "tests_per_s": round(npix * nf / (ms * 1e-3), 1),
@@ -203,14 +203,14 @@ def extra_workloads(rt3, r, np):
     r.set_spheres(cr, mats)
     cam = rt3.Camera().look_at(1920, 1080, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
     path("config 4: 100 000 spheres, 1920x1080, 16 of 256 spp, depth 50", cam,
-         rt3.make_params(1920, 1080, spp=16, max_depth=50, flags=rt3.FLAG_GAMMA2), "k_trace_mfma_tiled<spheres>")
+         rt3.make_params(1920, 1080, spp=16, max_depth=50, flags=rt3.FLAG_GAMMA2), "k_trace_mfma_tiled<spheres> (v_mfma_f32_16x16x32_bf16)")
     # config 5: Cornell-style box, 47 106 triangles, emissive quad
     faces, verts, fm = rt3.scene_cornell(64)
     r.set_spheres(*no_sph)
     r.set_mesh(faces, verts, fm)
     cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
     path("config 5: Cornell-style box, %d triangles, emissive quad, 1024x1024, 32 of 2048 spp, depth 50" % len(faces), cam,
-         rt3.make_params(1024, 1024, spp=32, max_depth=50, flags=rt3.FLAG_GAMMA2 | rt3.FLAG_BLACK_BACKGROUND), "k_trace_mfma_tiled<faces>")
+         rt3.make_params(1024, 1024, spp=32, max_depth=50, flags=rt3.FLAG_GAMMA2 | rt3.FLAG_BLACK_BACKGROUND), "k_trace_mfma_tiled<faces> (v_mfma_f32_16x16x32_bf16)")
     r.set_mesh(empty_f, empty_v)
     return out
 
@@ -295,7 +295,7 @@ def main():
         value = samples / (elapsed / args.steps) / 1e6
         n_launch = max(1, launches)
         k_ms = trace_ms / n_launch                                       # average duration of one k_trace launch on THIS rank (HIP events)
-        mfma_tf = st.mfma_instructions * FLOP_PER_MFMA / n_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        mfma_tf = st.mfma_instructions * float(st.mfma_flop_per_instruction) / n_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         alg_tf = st.prim_tests * FLOP_PER_SPHERE_TEST / n_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         hbm_bytes = st.samples * 12.0 / n_launch                         # algorithmic HBM bytes per launch: one 12-B radiance record per sample
         fingerprint = source_fingerprint()

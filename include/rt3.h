@@ -105,8 +105,8 @@ typedef struct rt3_stats {
     float    total_ms;           /* first launch -> last launch of the call (device time)            */
     uint32_t launches;           /* launches of the dominant kernel                                  */
     uint32_t n_spheres, n_faces;
-    uint32_t _pad;
-    uint64_t mfma_instructions;  /* v_mfma_f32_32x32x16_bf16 wave-instructions issued by the candidate filter (0: VALU scan) */
+    uint32_t mfma_flop_per_instruction;   /* 32768 (v_mfma_f32_32x32x16_bf16: k_trace_mfma) or 16384 (v_mfma_f32_16x16x32_bf16: tiled kernels) */
+    uint64_t mfma_instructions;  /* bf16 MFMA wave-instructions issued by the candidate filter (0: VALU scan / brute force) */
     uint64_t exact_tests;        /* (ray, primitive) pairs that survived the filter and went through the exact test
                                     (counted by the tiled matrix-filter kernels; 0 elsewhere)                            */
 } rt3_stats;

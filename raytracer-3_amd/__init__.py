@@ -54,7 +54,7 @@ class rt3_params(C.Structure):
 class rt3_stats(C.Structure):
     _fields_ = [("ray_casts", C.c_uint64), ("prim_tests", C.c_uint64), ("samples", C.c_uint64),
                 ("trace_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint32),
-                ("n_spheres", C.c_uint32), ("n_faces", C.c_uint32), ("_pad", C.c_uint32), ("mfma_instructions", C.c_uint64),
+                ("n_spheres", C.c_uint32), ("n_faces", C.c_uint32), ("mfma_flop_per_instruction", C.c_uint32), ("mfma_instructions", C.c_uint64),
                 ("exact_tests", C.c_uint64)]
 
 

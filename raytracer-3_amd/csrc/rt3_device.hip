@@ -57,7 +57,7 @@ struct rt3_ctx {
     rt3_material* d_face_mats_in = nullptr; uint32_t* d_error = nullptr;
     // spheres
     uint32_t n_sph = 0;
-    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
+    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag16 = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
     // work buffers
     Rgb* d_rad = nullptr; size_t rad_entries = 0;
@@ -82,6 +82,7 @@ struct rt3_ctx {
     hipStream_t last_stream = nullptr;
     uint64_t last_samples = 0;
     bool last_was_path = false;
+    bool last_mfma16 = false;                                       // the last trace kernel was a tiled one (16x16x32 MFMAs)
     bool rendered = false;
     // what the render in flight will report once its last launch has been issued (committed only then)
 };
@@ -207,6 +208,24 @@ std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n)
     return out;
 }
 
+// The same rows as fragments of the 16x16x32 form (tiled kernels): [row block][operand 2 h + q][lane 16 g + c] x 8 bf16.
+std::vector<uint32_t> build_sphere_frags16(const float* center_radius, uint32_t n) {
+    const uint32_t blocks = (n + 31u) / 32u;
+    std::vector<uint32_t> out((size_t)blocks * 4 * 64 * 4, 0u);
+    for (uint32_t j = 0; j < blocks * 32; j++) {
+        uint32_t fr[2][4][4];
+        if (j < n) {
+            const float* s = center_radius + 4 * (size_t)j;
+            const double c2 = (double)s[0] * s[0] + (double)s[1] * s[1] + (double)s[2] * s[2], r2 = (double)s[3] * s[3];
+            bound_frag16_row(s[0], s[1], s[2], filter_kj(c2, r2), fr);
+        } else bound_frag16_row(0.0f, 0.0f, 0.0f, kNeverCandidate, fr);
+        for (uint32_t q = 0; q < 2; q++)
+            for (uint32_t g = 0; g < 4; g++)
+                std::memcpy(&out[frag16_index(j / 32, j % 32, q, g) * 4], fr[q][g], 16);
+    }
+    return out;
+}
+
 bool row_owned(const rt3_params* p, uint32_t y) {
     if (p->tile_count <= 1) return true;
     return ((y / p->tile_rows) % p->tile_count) == p->tile_index;
@@ -283,7 +302,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
+    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag16, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -426,7 +445,8 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
         kind[i] = materials[i].kind;
     }
     int rc;
-    if ((rc = upload(ctx, &ctx->d_sph_frag, build_sphere_frags(center_radius, n)))) return rc;
+    if ((rc = upload(ctx, &ctx->d_sph_frag, build_sphere_frags(center_radius, n)))) return rc;        // k_trace_mfma (32x32x16 form)
+    if ((rc = upload(ctx, &ctx->d_sph_frag16, build_sphere_frags16(center_radius, n)))) return rc;    // tiled kernels (16x16x32 form)
     if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
         (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
         return rc;
@@ -662,7 +682,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
         RT3_HIP(hipEventRecord(a, stream));
         if (mfma_single) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
-        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag);
+        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag16);
         else hipLaunchKernelGGL(plain, dim3(grid), dim3(kBlock), lds, stream, A);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipEventRecord(b, stream));
@@ -678,6 +698,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     ctx->last_stream = stream;
     ctx->last_samples = (uint64_t)npix * sample_count;
     ctx->last_was_path = true;
+    ctx->last_mfma16 = tiled != nullptr;
     ctx->rendered = true;
     ctx->acc_valid = true; ctx->acc_params = *p; ctx->acc_cam = *cam; ctx->acc_done = sample_begin + sample_count; ctx->acc_npix = npix;
     return 0;
@@ -833,6 +854,7 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
         out->ray_casts = counters[0];
         out->prim_tests = counters[0] * ((uint64_t)ctx->n_sph + ctx->n_faces);
         out->mfma_instructions = counters[1];
+        out->mfma_flop_per_instruction = counters[1] ? (ctx->last_mfma16 ? 16384u : 32768u) : 0u;
 #ifndef RT3_PROFILE
         out->exact_tests = counters[2];
 #endif

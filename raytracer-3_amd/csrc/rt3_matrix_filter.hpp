@@ -209,6 +209,144 @@ __device__ __forceinline__ void mfma_flush(uint32_t nz, uint32_t n_blocks, const
     while (cand_next(it, bm, row)) eval(row);
 }
 // ------------------------------------------------------------------------------------------------------
+// The same filter on v_mfma_f32_16x16x32_bf16 — the form the tiled kernels and k_mode_r_mfma run
+// ------------------------------------------------------------------------------------------------------
+// Under this load the chip is clock-limited, and it holds a higher clock on the 16x16x32 shape: tools/ubench_mfma_shape.hip — the
+// scan's instruction mix (4 ds_read_b128 + K = 64 of MFMA + 32 v_alignbit per 32 rows x 64 rays, four waves per SIMD, random operands) —
+// sustains 1530 TFLOP/s with 8 x 32x32x16 and 1720 with 16 x 16x16x32 (MI355X_MICROARCH.md, DVFS give-back, item 7).  Same products,
+// other K order: the 64 K-slots are six groups of ten, (ray part of terms 0..8, c) x (sphere part of terms 0..8, c'):
+//     A  (H x, 1)   x (H y, H K)      B  (H x, 1)   x (M y, M K)      C  (H x, 1)   x (L y, L K)
+//     D  (M x, H E) x (H y, 1)        E  (M x, M E) x (M y, 1)        F  (L x, L E) x (H y, 1)        + four empty slots
+// so the ray side of a group is five dwords the three-way split produces anyway: (ph0..ph3, h8), (pm0..pm3, m8a | m8b), (pl0..pl3, l8).
+// Operand (h, q) of a row block holds rows 16 h .. 16 h + 15 (= spheres 32 blk + 16 h + c, natural order), K-slots 32 q .. 32 q + 31;
+// lane (g, c) = 16 g + c supplies row / column c, K-slots 32 q + 8 g .. + 7, and receives rows 4 g .. 4 g + 3 of column c.
+// A lane therefore ends a row block with 8 results (h, j) for each of FOUR rays 16 G + c: its candidate word is bit 8 G + 4 h + j <->
+// (ray lane 16 G + c, sphere 16 h + 4 g + j).  It is not the word of the lane's own ray, and need not be: the pair list takes (ray lane,
+// primitive) pairs from whichever lane found them.
+// (Folding the 16 results of a half block with 8 v_max3_i32 first and decoding only when some lane's maximum has its sign bit clear —
+// 18 % of the half blocks on the 100 000-sphere scene — was built and measured x1.019 / x1.024 slower, although a bare loop gains 8 %.)
+struct RayOperands16 { u32x4 b[4][2]; };                            // [ray group G][q]: K-slice of this lane's group for ray 16 G + c
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// Sphere side: out[q][g][dword] = K-slots 32 q + 8 g .. + 7 of one row (kj, never / always: as bound_frag_row).
+__host__ __device__ inline void bound_frag16_row(float cx, float cy, float cz, float kj, uint32_t out[2][4][4]) {
+    uint32_t y[9][3], k[3];                                         // [term][part]
+    const double x = cx, yy = cy, z = cz;
+    split3((float)(x * x), y[0]); split3((float)(yy * yy), y[1]); split3((float)(z * z), y[2]);
+    split3((float)(x * yy), y[3]); split3((float)(x * z), y[4]); split3((float)(yy * z), y[5]);
+    split3(cx, y[6]); split3(cy, y[7]); split3(cz, y[8]);
+    split3(kj, k);
+    const uint32_t one = 0x3F80u;
+    uint32_t slot[64];
+    const int part_of_group[6] = { 0, 1, 2, 0, 1, 0 };              // sphere part of groups A..F
+    for (int grp = 0; grp < 6; grp++) {
+        for (int t = 0; t < 9; t++) slot[10 * grp + t] = y[t][part_of_group[grp]];
+        slot[10 * grp + 9] = grp < 3 ? k[grp] : one;
+    }
+    for (int i = 60; i < 64; i++) slot[i] = 0u;
+    for (int q = 0; q < 2; q++)
+        for (int g = 0; g < 4; g++)
+            for (int d = 0; d < 4; d++) out[q][g][d] = slot[32 * q + 8 * g + 2 * d] | (slot[32 * q + 8 * g + 2 * d + 1] << 16);
+}
+// where the fragment of (row block, row b of it, q, lane group g) lives: [blk][operand 2 h + q][lane 16 g + c]
+__host__ __device__ constexpr size_t frag16_index(uint32_t blk, uint32_t b, uint32_t q, uint32_t g) {
+    return ((size_t)blk * 4 + 2u * (b >> 4) + q) * 64 + 16u * g + (b & 15u);
+}
+
+// v_permlane16_swap(x, y): x's odd 16-lane rows <-> y's even rows
+__device__ __forceinline__ void swap16(uint32_t x, uint32_t y, uint32_t& nx, uint32_t& ny) {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    nx = r[0]; ny = r[1];
+}
+// Ray side.  Every lane splits the ten factors of ITS ray as build_ray_operands does, which gives the 32 dwords D of its K vector;
+// lane (g, c) then needs dwords 16 q + 4 g .. + 3 of the rays of lanes (G, c), G = 0..3: a 4 x 4 transpose of 8-dword pieces across the
+// four 16-lane rows, done in two stages (half-waves with v_permlane32_swap, then rows with v_permlane16_swap) after which register
+// (source group G = 2 s + p) is the same register in every lane.
+__device__ __forceinline__ void build_ray_operands16(float ox, float oy, float oz, float dx, float dy, float dz, bool alive, RayOperands16& R) {
+    const float od = dotf(ox, oy, oz, dx, dy, dz), oo = dotf(ox, oy, oz, ox, oy, oz);
+    float x[9] = { dx * dx, dy * dy, dz * dz, 2.0f * dx * dy, 2.0f * dx * dz, 2.0f * dy * dz,
+                   2.0f * (ox - od * dx), 2.0f * (oy - od * dy), 2.0f * (oz - od * dz) };
+    float e = alive ? od * od - oo * (1.0f - kFilterEps) : -3e30f;      // a dead lane's column can never produce a candidate
+    uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ph[i] = pk_bf16(x[2 * i], x[2 * i + 1]); x[2 * i] -= pk_lo(ph[i]); x[2 * i + 1] -= pk_hi(ph[i]); }
+    const uint32_t h8 = pk_bf16(x[8], 1.0f);
+    x[8] -= pk_lo(h8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { pm[i] = pk_bf16(x[2 * i], x[2 * i + 1]); x[2 * i] -= pk_lo(pm[i]); x[2 * i + 1] -= pk_hi(pm[i]); }
+    const uint32_t m8a = pk_bf16(x[8], e);
+    e -= pk_hi(m8a);
+    const uint32_t m8b = pk_bf16(x[8], e);
+    e -= pk_hi(m8b);
+    x[8] -= pk_lo(m8a);
+#pragma unroll
+    for (int i = 0; i < 4; i++) pl[i] = pk_bf16(x[2 * i], x[2 * i + 1]);
+    const uint32_t l8 = pk_bf16(x[8], e);
+    // the K vector in dwords: groups A, B, C = (ph0..3, h8) three times, D = (pm0..3, m8a), E = (pm0..3, m8b), F = (pl0..3, l8), two empty
+    const uint32_t D[32] = { ph[0], ph[1], ph[2], ph[3], h8, ph[0], ph[1], ph[2], ph[3], h8, ph[0], ph[1], ph[2], ph[3], h8,
+                             pm[0], pm[1], pm[2], pm[3], m8a, pm[0], pm[1], pm[2], pm[3], m8b, pl[0], pl[1], pl[2], pl[3], l8, 0u, 0u };
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // what this lane sends to lane group g: D[16 q + 4 g + i].  Stage 1 delivers across the half-waves ...
+            uint32_t x0, y0, x1, y1;
+            swap32(D[16 * q + i], D[16 * q + 8 + i], x0, y0);           // destinations g = 0 | 2
+            swap32(D[16 * q + 4 + i], D[16 * q + 12 + i], x1, y1);      // destinations g = 1 | 3
+            // ... now x* = from the lower half-wave, y* = from the upper one; stage 2 delivers across the rows of a half-wave
+            uint32_t s0e, s0o, s1e, s1o;
+            swap16(x0, x1, s0e, s0o);                                   // source half 0: from its even row (G = 0), from its odd row (G = 1)
+            swap16(y0, y1, s1e, s1o);                                   // source half 1: G = 2, G = 3
+            R.b[0][q][i] = s0e; R.b[1][q][i] = s0o; R.b[2][q][i] = s1e; R.b[3][q][i] = s1o;
+        }
+}
+
+// The scan of one LDS-resident tile of up to 16 row blocks with the 16x16x32 shape.  Candidate word `blk` of this LANE (see above: four
+// rays x eight rows) goes to bm[blk * STRIDE], bit CLEAR <-> candidate; the return value has bit (n_blocks - 1 - blk) set when that word
+// holds any candidate.  Per row block: 4 ds_read_b128, 16 MFMAs, 32 v_alignbit.
+template <uint32_t STRIDE = kMB>
+__device__ __forceinline__ uint32_t mfma16_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands16& R, uint32_t* bm, uint32_t lane) {
+    uint32_t nz = 0;
+    if (n_blocks == 0) return nz;
+    const u32x4* fr = s_frag + lane;
+    u32x4 a00 = fr[0], a01 = fr[64], a10 = fr[128], a11 = fr[192];  // [h][q]
+    auto mm = [](const u32x4& a, const u32x4& b, const f32x4v& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {
+        uint32_t* bm0 = bm + b0 * STRIDE;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            if (b0 + u >= n_blocks) break;
+            const f32x4v zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+            uint32_t n = 0xFFFFFFFFu;
+            // ray groups 3, 2 first, then 1, 0: the sign bits are shifted in from the top, bit 8 G + 4 h + j
+#pragma unroll
+            for (int gp = 1; gp >= 0; gp--) {
+                const int G1 = 2 * gp + 1, G0 = 2 * gp;
+                f32x4v d11 = mm(a10, R.b[G1][0], zero), d01 = mm(a00, R.b[G1][0], zero), d10 = mm(a10, R.b[G0][0], zero), d00 = mm(a00, R.b[G0][0], zero);
+                d11 = mm(a11, R.b[G1][1], d11); d01 = mm(a01, R.b[G1][1], d01); d10 = mm(a11, R.b[G0][1], d10); d00 = mm(a01, R.b[G0][1], d00);
+                if (gp == 0 && b0 + u + 1 < n_blocks) {                 // next block's fragments, in flight during the decode below
+                    const u32x4* fn = fr + (size_t)(b0 + u + 1) * 256;
+                    a00 = fn[0]; a01 = fn[64]; a10 = fn[128]; a11 = fn[192];
+                }
+#pragma unroll
+                for (int j = 3; j >= 0; j--) n = __builtin_amdgcn_alignbit(n, __float_as_uint(d11[j]), 31);
+#pragma unroll
+                for (int j = 3; j >= 0; j--) n = __builtin_amdgcn_alignbit(n, __float_as_uint(d01[j]), 31);
+#pragma unroll
+                for (int j = 3; j >= 0; j--) n = __builtin_amdgcn_alignbit(n, __float_as_uint(d10[j]), 31);
+#pragma unroll
+                for (int j = 3; j >= 0; j--) n = __builtin_amdgcn_alignbit(n, __float_as_uint(d00[j]), 31);
+            }
+            bm0[u * STRIDE] = n;
+            asm("v_cmp_ne_u32_e32 vcc, -1, %1\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(nz) : "v"(n) : "vcc");
+        }
+    }
+    return nz;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Exact tests at full lane utilisation: the candidates of a wave's 64 rays are compacted into a (ray lane, primitive) pair list
 // ------------------------------------------------------------------------------------------------------
 // A ray has few candidates but they cluster (a ray skimming a tessellated wall meets dozens of bounding spheres in one tile while its
@@ -219,13 +357,9 @@ __device__ __forceinline__ void mfma_flush(uint32_t nz, uint32_t n_blocks, const
 // one 64-bit ds_min: key = (t bits, sphere?, primitive index, sign of t), so the minimum IS the sequential loops' answer (nearest t;
 // on equal t faces before spheres, then the lower index) whatever order the pairs are tested in.  t >= 0 always (t_min >= 0 is checked
 // by the host), so its bit pattern with the sign cleared orders like the number; the sign of a -0.0 rides in the lowest bit.
-// WHEN the tests run matters as much: a test phase is two dependent trips to L2 (2-3 us), and the 16 waves of a workgroup meet at two
-// barriers per tile — a wave that tests on its own, whenever its list happens to fill, makes the other 15 wait (with 21 pairs per tile
-// and wave on the 47k-face scene some wave did so at nearly every tile: the matrix pipe was 50 % busy there against 70 % on a scene
-// with few candidates).  So the workgroup tests TOGETHER: a wave that holds kPairTrigger pairs raises a flag in LDS, and at the next
-// tile every wave works off whatever it holds — between the tile's two barriers, while the loads that fill the tile are in flight.
-constexpr uint32_t kPairCap = 192;                                  // per wave: up to 127 waiting + one round of <= 64 new pairs
-constexpr uint32_t kPairTrigger = 48;                               // a wave holding this many asks the workgroup for a test phase
+// (Running the tests of all 16 waves together, in a phase of the whole workgroup behind a tile's first barrier, instead of whenever a wave
+// has 64 pairs, was built and measured neutral — x1.001 / x0.990 / x0.993 on the three tiled workloads — and taken out again.)
+constexpr uint32_t kPairCap = 128;                                  // per wave: < 64 left over + one round of <= 64 new pairs
 constexpr uint32_t kPairLaneShift = 26;                             // pair = lane << 26 | primitive row (< 2^26)
 constexpr unsigned long long kKeyNone = 0x7F800000FFFFFFFFull;      // t = +inf: what a real hit (t < inf) always beats
 __device__ __forceinline__ unsigned long long hit_key(float t, uint32_t is_sphere, uint32_t idx) {
@@ -264,21 +398,25 @@ __device__ __forceinline__ void test_all(uint32_t lane, const uint32_t* pairs, u
         n_pairs = 0u;
     }
 }
-// Pushes this lane's candidates of the tile just scanned (rows row0 ..) into the wave's list; n_pairs (wave-uniform) is the fill.
-// Tests run at the workgroup's test phases (see the tiled kernels); only a list about to overflow is worked off on the spot.
+// Pushes this lane's candidates of the tile just scanned (rows row0 ..) into the wave's list and tests 64 pairs whenever that many are
+// there; n_pairs (wave-uniform) carries the remainder to the next tile.  The words are mfma16_scan_tile's: bit 8 G + 4 h + j of word blk
+// is (ray lane 16 G + c, row 32 blk + 16 h + 4 g + j), with (g, c) the pushing lane's own position.
 template <uint32_t STRIDE = kMB, class Test>
-__device__ __forceinline__ void push_pairs(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
-                                           uint32_t& n_pairs, Test&& test) {
+__device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
+                                             uint32_t& n_pairs, Test&& test) {
     CandIter it = { nz, 0u, 0u, n_blocks };
+    const uint32_t c = lane & 15u, g4 = (lane >> 4) * 4u;
     for (;;) {
-        uint32_t row = 0;
-        const bool have = cand_next<STRIDE>(it, bm, row);
+        uint32_t pos = 0;                                           // 32 blk + bit
+        const bool have = cand_next<STRIDE>(it, bm, pos);
         const unsigned long long m = __ballot(have);
         if (m == 0ull) break;
-        if (have) pairs[n_pairs + prefix_count(m)] = (lane << kPairLaneShift) | (row0 + row);
+        const uint32_t bit = pos & 31u;
+        const uint32_t row = row0 + (pos & ~31u) + ((bit & 4u) << 2) + g4 + (bit & 3u), ray_lane = ((bit >> 3) << 4) + c;
+        if (have) pairs[n_pairs + prefix_count(m)] = (ray_lane << kPairLaneShift) | row;
         n_pairs += (uint32_t)__popcll(m);
-        __builtin_amdgcn_wave_barrier();                            // (LDS serves one wave's requests in order; this only pins the compiler)
-        if (n_pairs > kPairCap - 64u) {
+        __builtin_amdgcn_wave_barrier();
+        if (n_pairs >= 64u) {
             n_pairs -= 64u;
             test(pairs[n_pairs + lane], true);
             __builtin_amdgcn_wave_barrier();
@@ -386,16 +524,13 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
 // workgroup move through the tiles together (two barriers per tile); candidates go through the pair list above, the exact tests
 // gather their records from global memory, all 64 lanes at a time.
 // REF: RT3_FLAG_REFERENCE_PRIMARY (camera at the origin, no lens: checked by the host).
-constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4 + 16;
-// One tile of fragments through the workgroup: [barrier] loads -> `between()` -> LDS stores [barrier].  `between` is where a test phase
-// runs, its memory traffic overlapping the fill's.
-template <class Between>
-__device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict__ src, uint32_t n_vec, uint32_t tid, Between&& between) {
-    __syncthreads();                                                // every wave is done with the previous tile (and has posted its wish to test)
+constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;
+// One tile of fragments through the workgroup: [barrier] loads -> LDS stores [barrier].
+__device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict__ src, uint32_t n_vec, uint32_t tid) {
+    __syncthreads();                                                // every wave is done with the previous tile
     u32x4 v[4];
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++) v[i] = src[min(tid + i * kMB, n_vec - 1u)];       // unconditional: four loads in flight, no branches
-    between();
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++) { const uint32_t k = tid + i * kMB; if (k < n_vec) s_frag[k] = v[i]; }
     __syncthreads();
@@ -407,12 +542,9 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);           // [16][kMB] candidate words
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kMB);   // [kMB] nearest hit of every lane's ray
     uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kMB);              // [16 waves][kPairCap]
-    uint32_t* s_flag = s_pairs + (kMB / 64) * kPairCap;                        // [2] "some wave wants a test phase at the next tile", by tile parity
     const uint32_t tid = threadIdx.x, lane = lane_id();
     uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
     unsigned long long* keys = s_key + (tid & ~63u);                           // this wave's 64 records
-    if (tid < 2) s_flag[tid] = 0u;                                             // (the first barrier of the loop below publishes it)
-    uint32_t parity = 0;                                                       // workgroup-uniform tile counter & 1
 
     Path P;
     P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
@@ -437,30 +569,24 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
         LaneRay ray = { P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, REF && P.depth == 0 };
         float ux = ray.dx, uy = ray.dy, uz = ray.dz;                            // what the filter sees: always a unit direction
         if (REF && ray.literal) { const float inv = 1.0f / __builtin_sqrtf(dot3(ux, uy, uz, ux, uy, uz)); ux = ux * inv; uy = uy * inv; uz = uz * inv; }
-        RayOperands R;
-        build_ray_operands(ray.ox, ray.oy, ray.oz, ux, uy, uz, alive, R);
+        RayOperands16 R;
+        build_ray_operands16(ray.ox, ray.oy, ray.oz, ux, uy, uz, alive, R);
         keys[lane] = kKeyNone;
         uint32_t n_pairs = 0;
 
         auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& test) {
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
-            for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16, parity ^= 1u) {
+            for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
                 const uint32_t nb = min(16u, total_blocks - b0);
                 RT3_PHASE(pt_rest)
-                fill_tile(s_frag, frags + (size_t)b0 * 256, nb * 256, tid, [&]() {
-                    RT3_PHASE(pt_fill)
-                    if (s_flag[parity] != 0u) test_all(lane, pairs, n_pairs, test);         // workgroup-uniform: a test phase for everybody
-                    RT3_PHASE(pt_test)
-                });
+                fill_tile(s_frag, frags + (size_t)b0 * 256, nb * 256, tid);
                 RT3_PHASE(pt_fill)
-                if (tid == 0) s_flag[parity] = 0u;                              // everybody has read it (second barrier); it is set again two barriers from now
                 if (live == 0ull) continue;                                     // a wave without rays (the tail of a launch) only keeps the barriers
-                const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
+                const uint32_t nz = mfma16_scan_tile(s_frag, nb, R, s_bm + tid, lane);
                 RT3_PHASE(pt_scan)
-                push_pairs(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
-                if (n_pairs >= kPairTrigger) s_flag[parity ^ 1u] = 1u;
+                push_pairs16(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
                 RT3_PHASE(pt_push)
-                mfmas += nb * 8ull;
+                mfmas += nb * 16ull;
             }
             test_all(lane, pairs, n_pairs, test);                               // what is left at the end of the pass
             RT3_PHASE(pt_test)
@@ -520,12 +646,9 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kMB);
     uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kMB);
-    uint32_t* s_flag = s_pairs + (kMB / 64) * kPairCap;
     const uint32_t tid = threadIdx.x, lane = lane_id();
     uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
     unsigned long long* keys = s_key + (tid & ~63u);
-    if (tid < 2) s_flag[tid] = 0u;
-    uint32_t parity = 0;
     const uint32_t pixel = blockIdx.x * kMB + tid;
     const bool valid_px = pixel < width * height;
     const uint32_t x = valid_px ? pixel % width : 0u, y = valid_px ? pixel / width : 0u;
@@ -536,8 +659,8 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
     const float dy = ((cam.ly + u * cam.hy) + v * cam.vy) - oy;
     const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
     const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));     // unit direction for the filter only
-    RayOperands R;
-    build_ray_operands(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid_px, R);
+    RayOperands16 R;
+    build_ray_operands16(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid_px, R);
     const LaneRay ray = { ox, oy, oz, dx, dy, dz, true };
     keys[lane] = kKeyNone;
     uint32_t n_pairs = 0;
@@ -555,15 +678,11 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
         if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
     };
     const uint32_t total_blocks = (n_faces + 31u) / 32u;
-    for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16, parity ^= 1u) {
+    for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
         const uint32_t nb = min(16u, total_blocks - b0);
-        fill_tile(s_frag, tri_frags + (size_t)b0 * 256, nb * 256, tid, [&]() {
-            if (s_flag[parity] != 0u) test_all(lane, pairs, n_pairs, test);
-        });
-        if (tid == 0) s_flag[parity] = 0u;
-        const uint32_t nz = mfma_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-        push_pairs(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
-        if (n_pairs >= kPairTrigger) s_flag[parity ^ 1u] = 1u;
+        fill_tile(s_frag, tri_frags + (size_t)b0 * 256, nb * 256, tid);
+        const uint32_t nz = mfma16_scan_tile(s_frag, nb, R, s_bm + tid, lane);
+        push_pairs16(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
     }
     test_all(lane, pairs, n_pairs, test);
     __builtin_amdgcn_wave_barrier();

@@ -69,14 +69,14 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
                               float4* __restrict__ mat, uint32_t* __restrict__ kind, uint32_t* __restrict__ error_flag,
                               u32x4* __restrict__ frag, uint32_t n_frag_rows) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    // matrix-filter fragments: row i of block i/32, for all four operands and both lane halves (padding rows: never candidates)
+    // matrix-filter fragments (16x16x32 form): row i of block i/32, both K halves, all four lane groups (padding rows: never candidates)
     auto write_frag = [&](float cx, float cy, float cz, float kj) {
         if (i >= n_frag_rows) return;
-        uint32_t fr[4][2][4];
-        bound_frag_row(cx, cy, cz, kj, fr);
-        for (int q = 0; q < 4; q++)
-            for (int hh = 0; hh < 2; hh++)
-                frag[((size_t)(i / 32) * 4 + q) * 64 + hh * 32 + frag_row_of(i % 32)] = u32x4{ fr[q][hh][0], fr[q][hh][1], fr[q][hh][2], fr[q][hh][3] };
+        uint32_t fr[2][4][4];
+        bound_frag16_row(cx, cy, cz, kj, fr);
+        for (uint32_t q = 0; q < 2; q++)
+            for (uint32_t g = 0; g < 4; g++)
+                frag[frag16_index(i / 32, i % 32, q, g)] = u32x4{ fr[q][g][0], fr[q][g][1], fr[q][g][2], fr[q][g][3] };
     };
     if (i >= n_pad && i >= n_frag_rows) return;
     if (i >= n_faces) { if (i < n_pad) bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }

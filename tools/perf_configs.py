@@ -27,10 +27,10 @@ def run_path(r, name, cam, params, reps=1):
         row = dict(config=name, samples=st.samples, ray_casts=st.ray_casts, prim_tests=st.prim_tests, kernel_ms=round(st.trace_ms, 3),
                    total_ms=round(st.total_ms, 3), wall_ms=round(wall * 1e3, 3), launches=st.launches,
                    msamples_per_s=round(st.samples / st.total_ms / 1e3, 1), gtests_per_s=round(st.prim_tests / st.trace_ms / 1e6, 1),
-                   mfma=st.mfma_instructions, mfma_frac_of_2500TF=round(st.mfma_instructions * 32768.0 / (st.trace_ms * 1e-3) / 2.5e15, 4),
+                   mfma=st.mfma_instructions, mfma_frac_of_2500TF=round(st.mfma_instructions * float(st.mfma_flop_per_instruction) / (st.trace_ms * 1e-3) / 2.5e15, 4),
                    exact_per_cast=round(st.exact_tests / max(1, st.ray_casts), 2),
                    # MFMA work is per wave whatever the number of live lanes: tests the matrix cores evaluated / tests that were needed
-                   lane_efficiency=round(st.prim_tests / max(1.0, st.mfma_instructions / 8.0 * 32 * 64), 4))
+                   lane_efficiency=round(st.prim_tests / max(1.0, st.mfma_instructions * st.mfma_flop_per_instruction / 32768.0 / 8.0 * 32 * 64), 4))
         if best is None or row["total_ms"] < best["total_ms"]:
             best = row
     print(json.dumps(best), flush=True)

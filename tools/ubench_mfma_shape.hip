@@ -17,7 +17,7 @@ __device__ __forceinline__ u32x4 rnd4(unsigned& s) {           // four dwords of
     return v;
 }
 
-template <int SHAPE>                                            // 32: 32x32x16, 16: 16x16x32
+template <int SHAPE, int DECODE = 2, int READS = 1>            // SHAPE 32: 32x32x16, 16: 16x16x32; DECODE 2: 32 v_alignbit, 1: 16 v_max3_f32, 0: none; READS: operand fragments re-read from LDS
 __global__ __launch_bounds__(1024) void k(unsigned* out, int iters) {
     __shared__ u32x4 lds[4096];
     const unsigned t = threadIdx.x;
@@ -59,11 +59,21 @@ __global__ __launch_bounds__(1024) void k(unsigned* out, int iters) {
                 d[G] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(a1), bf(b[2 * G + 1]), d[G], 0, 0, 0);
                 d[4 + G] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(a3), bf(b[2 * G + 1]), d[4 + G], 0, 0, 0);
             }
-            a0 = f[0]; a1 = f[64]; a2 = f[128]; a3 = f[192];
+            if (READS) { a0 = f[0]; a1 = f[64]; a2 = f[128]; a3 = f[192]; }
             FENCE;
+            if (DECODE == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                for (int g = 0; g < 4; g++) { n0 = __builtin_amdgcn_alignbit(n0, __float_as_uint(d[i][g]), 31); n1 = __builtin_amdgcn_alignbit(n1, __float_as_uint(d[4 + i][g]), 31); }
+                for (int i = 0; i < 4; i++)
+                    for (int g = 0; g < 4; g++) { n0 = __builtin_amdgcn_alignbit(n0, __float_as_uint(d[i][g]), 31); n1 = __builtin_amdgcn_alignbit(n1, __float_as_uint(d[4 + i][g]), 31); }
+            } else if (DECODE == 1) {
+                float m = __builtin_fmaxf(d[0][0], d[0][1]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i == 0) m = __builtin_fmaxf(__builtin_fmaxf(m, d[0][2]), d[0][3]);
+                    else { m = __builtin_fmaxf(__builtin_fmaxf(m, d[i][0]), d[i][1]); m = __builtin_fmaxf(__builtin_fmaxf(m, d[i][2]), d[i][3]); }
+                }
+                n0 ^= __float_as_uint(m);
+            } else { n0 ^= __float_as_uint(d[0][0] + d[7][3]); }
         }
         FENCE;
         acc += n0 ^ n1;
@@ -71,25 +81,27 @@ __global__ __launch_bounds__(1024) void k(unsigned* out, int iters) {
     out[blockIdx.x * 1024 + t] = acc;
 }
 
-template <int SHAPE>
+template <int SHAPE, int DECODE = 2, int READS = 1>
 void run(unsigned* d_out, int cus) {
     const int iters = 40000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<SHAPE><<<cus, 1024>>>(d_out, 2000);
+    k<SHAPE, DECODE, READS><<<cus, 1024>>>(d_out, 2000);
     hipEventRecord(e0);
-    k<SHAPE><<<cus, 1024>>>(d_out, iters);
+    k<SHAPE, DECODE, READS><<<cus, 1024>>>(d_out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = (double)cus * 16 * iters * 8 * 32768;
     const double tf = flop / (ms * 1e-3) / 1e12;
-    printf("%s + 4 ds_read_b128 + 32 v_alignbit per 32x64 block: %8.2f ms  %7.1f TFLOP/s bf16 (%.1f %% of 2500)\n",
-           SHAPE == 32 ? " 8 x v_mfma_f32_32x32x16_bf16" : "16 x v_mfma_f32_16x16x32_bf16", ms, tf, tf / 25.0);
+    printf("%s + %d ds_read_b128 + %s per 32x64 block: %8.2f ms  %7.1f TFLOP/s bf16 (%.1f %% of 2500)\n",
+           SHAPE == 32 ? " 8 x v_mfma_f32_32x32x16_bf16" : "16 x v_mfma_f32_16x16x32_bf16", READS ? 4 : 0,
+           DECODE == 2 ? "32 v_alignbit" : DECODE == 1 ? "16 v_max3_f32 " : "no decode   ", ms, tf, tf / 25.0);
 }
 
 int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     unsigned* d_out; hipMalloc(&d_out, (size_t)cus * 1024 * 4);
-    for (int rep = 0; rep < 3; rep++) { run<32>(d_out, cus); run<16>(d_out, cus); }
+    for (int rep = 0; rep < 2; rep++) { run<32>(d_out, cus); run<16>(d_out, cus); }
+    for (int rep = 0; rep < 2; rep++) { run<16, 1, 1>(d_out, cus); run<16, 0, 1>(d_out, cus); run<16, 2, 0>(d_out, cus); run<16, 0, 0>(d_out, cus); }
     return 0;
 }
