@@ -57,7 +57,7 @@ struct rt3_ctx {
     rt3_material* d_face_mats_in = nullptr; uint32_t* d_error = nullptr;
     // spheres
     uint32_t n_sph = 0;
-    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag16 = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
+    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
     // work buffers
     Rgb* d_rad = nullptr; size_t rad_entries = 0;
@@ -208,20 +208,20 @@ std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n)
     return out;
 }
 
-// The same rows as fragments of the 16x16x32 form (tiled kernels): [row block][operand 2 h + q][lane 16 g + c] x 8 bf16.
-std::vector<uint32_t> build_sphere_frags16(const float* center_radius, uint32_t n) {
+// The same spheres as fragments of the K = 32 form of the tiled kernels (rt3_matrix_filter.hpp): [row block][h][lane 16 g + c] x 8 bf16,
+// coordinates relative to `centre` (the centroid: it keeps |C|^2, and with it the filter's margin, small).
+std::vector<uint32_t> build_sphere_frags32(const float* center_radius, uint32_t n, const float centre[3]) {
     const uint32_t blocks = (n + 31u) / 32u;
-    std::vector<uint32_t> out((size_t)blocks * 4 * 64 * 4, 0u);
+    std::vector<uint32_t> out((size_t)blocks * 2 * 64 * 4, 0u);
     for (uint32_t j = 0; j < blocks * 32; j++) {
-        uint32_t fr[2][4][4];
+        uint32_t fr[4][4];
         if (j < n) {
             const float* s = center_radius + 4 * (size_t)j;
-            const double c2 = (double)s[0] * s[0] + (double)s[1] * s[1] + (double)s[2] * s[2], r2 = (double)s[3] * s[3];
-            bound_frag16_row(s[0], s[1], s[2], filter_kj(c2, r2), fr);
-        } else bound_frag16_row(0.0f, 0.0f, 0.0f, kNeverCandidate, fr);
-        for (uint32_t q = 0; q < 2; q++)
-            for (uint32_t g = 0; g < 4; g++)
-                std::memcpy(&out[frag16_index(j / 32, j % 32, q, g) * 4], fr[q][g], 16);
+            const float cx = (float)((double)s[0] - centre[0]), cy = (float)((double)s[1] - centre[1]), cz = (float)((double)s[2] - centre[2]);
+            const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz, r2 = (double)s[3] * s[3];
+            bound_frag32_row(cx, cy, cz, filter_kj32(c2, r2), fr);
+        } else bound_frag32_row(0.0f, 0.0f, 0.0f, kNeverCandidate, fr);
+        for (uint32_t g = 0; g < 4; g++) std::memcpy(&out[frag32_index(j / 32, j % 32, g) * 4], fr[g], 16);
     }
     return out;
 }
@@ -302,7 +302,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag16, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
+    void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -446,7 +446,12 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
     }
     int rc;
     if ((rc = upload(ctx, &ctx->d_sph_frag, build_sphere_frags(center_radius, n)))) return rc;        // k_trace_mfma (32x32x16 form)
-    if ((rc = upload(ctx, &ctx->d_sph_frag16, build_sphere_frags16(center_radius, n)))) return rc;    // tiled kernels (16x16x32 form)
+    double c0[3] = { 0.0, 0.0, 0.0 };
+    for (uint32_t i = 0; i < n; i++) for (int a = 0; a < 3; a++) c0[a] += center_radius[4 * (size_t)i + a];
+    for (int a = 0; a < 3; a++) ctx->sph_centre[a] = n ? (float)(c0[a] / n) : 0.0f;
+    if (!(std::isfinite(ctx->sph_centre[0]) && std::isfinite(ctx->sph_centre[1]) && std::isfinite(ctx->sph_centre[2])))
+        ctx->sph_centre[0] = ctx->sph_centre[1] = ctx->sph_centre[2] = 0.0f;
+    if ((rc = upload(ctx, &ctx->d_sph_frag32, build_sphere_frags32(center_radius, n, ctx->sph_centre)))) return rc;    // tiled kernels (K = 32 form)
     if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
         (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
         return rc;
@@ -619,6 +624,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         !fastdiv_ok(p->tile_count > 1 ? p->tile_rows : 1, p->height))
         return fail(ctx, RT3_E_DEVICE, "internal: magic-number division self-check failed");
     A.rad = ctx->d_rad; A.work_counter = ctx->d_work; A.cast_counter = ctx->d_casts;
+    A.fcx = ctx->sph_centre[0]; A.fcy = ctx->sph_centre[1]; A.fcz = ctx->sph_centre[2];
 
     // ---- which kernel
     //   brute         every ray against every primitive (debug switch / RT3_BRUTE=1; REFERENCE_PRIMARY with a camera off the origin or a lens)
@@ -682,7 +688,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
         RT3_HIP(hipEventRecord(a, stream));
         if (mfma_single) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
-        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag16);
+        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag32);
         else hipLaunchKernelGGL(plain, dim3(grid), dim3(kBlock), lds, stream, A);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipEventRecord(b, stream));

@@ -122,6 +122,7 @@ struct TraceArgs {
     uint32_t s0;             // first sample of this batch
     uint32_t total;          // npix * samples in this batch
     Rgb* rad;                // per-sample radiance, [sample in batch][owned pixel], 12 B each
+    float fcx, fcy, fcz;     // centre the K = 32 sphere filter's coordinates are taken about (the spheres' centroid)
     uint32_t* work_counter;
     unsigned long long* cast_counter;
 };

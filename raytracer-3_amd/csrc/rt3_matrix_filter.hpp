@@ -347,6 +347,104 @@ __device__ __forceinline__ uint32_t mfma16_scan_tile(const u32x4* s_frag, uint32
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The K = 32 form for analytic spheres: half the matrix work and half the operand bytes per test, a wider margin
+// ------------------------------------------------------------------------------------------------------
+// The tiled kernels run at the rate the chip sustains for their instruction mix, so what a test costs is its share of
+// MFMAs, LDS operand bytes and decode.  For spheres the exact test is cheap (one 16-byte record, ~45 instructions, 64 lanes at a time through
+// the pair list), so the filter may be coarser: only the products HH, MH, HM of the split factors (sphere part x ray part), K = 32 —
+// ONE v_mfma_f32_16x16x32_bf16 per 16 x 16 tile, two ds_read_b128 per row block — with eps = 2.2e-4 covering what is dropped (MM, LH, HL:
+// 3 * 2^-16 per term; bound in DESIGN.md 5.2c) and the coordinates taken about the spheres' centroid, which keeps |C|^2 + |o|^2, and with it
+// the margin, small.  K-slots: A (H x, 1) x (H y, H K) | B (H x, 1) x (M y, M K rounded UP) | D (M x, H E) x (H y, 1) | (M E, L E) x (1, 1).
+// Faces keep the K = 64 form: their exact test costs a 64-byte gather and ~150 instructions, and every extra candidate a push.
+constexpr float kFilterEps32 = 2.2e-4f;
+struct RayOperands32 { u32x4 b[4]; };                               // [ray group G]: K-slots 8 g .. 8 g + 7 of ray 16 G + c
+__host__ __device__ inline float filter_kj32(double c2, double r2) { return (float)((r2 - c2) + (double)kFilterEps32 * (c2 + r2)); }
+__host__ __device__ inline uint32_t bf16_ceil(float x) {           // smallest bf16 >= x (finite x)
+    uint32_t u = __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u;     // towards zero
+    if (x > 0.0f && __builtin_bit_cast(float, u) < x) u += 0x10000u;
+    return u >> 16;
+}
+// Sphere side: out[g][dword] = K-slots 8 g .. 8 g + 7 of one row; (cx, cy, cz) are already relative to the filter centre.
+__host__ __device__ inline void bound_frag32_row(float cx, float cy, float cz, float kj, uint32_t out[4][4]) {
+    uint32_t y[9][3], k[2];
+    const double x = cx, yy = cy, z = cz;
+    split3((float)(x * x), y[0]); split3((float)(yy * yy), y[1]); split3((float)(z * z), y[2]);
+    split3((float)(x * yy), y[3]); split3((float)(x * z), y[4]); split3((float)(yy * z), y[5]);
+    split3(cx, y[6]); split3(cy, y[7]); split3(cz, y[8]);
+    k[0] = bf16_rn(kj);
+    k[1] = bf16_ceil(kj - bf16_up(k[0]));                           // H K + M K >= kj: what the dropped low part would add stays on the safe side
+    const uint32_t one = 0x3F80u;
+    uint32_t slot[32];
+    for (int t = 0; t < 9; t++) { slot[t] = y[t][0]; slot[10 + t] = y[t][1]; slot[20 + t] = y[t][0]; }
+    slot[9] = k[0]; slot[19] = k[1]; slot[29] = one; slot[30] = one; slot[31] = one;
+    for (int g = 0; g < 4; g++)
+        for (int d = 0; d < 4; d++) out[g][d] = slot[8 * g + 2 * d] | (slot[8 * g + 2 * d + 1] << 16);
+}
+__host__ __device__ constexpr size_t frag32_index(uint32_t blk, uint32_t b, uint32_t g) {       // [blk][h][16 g + c]
+    return ((size_t)blk * 2 + (b >> 4)) * 64 + 16u * g + (b & 15u);
+}
+// Ray side (o relative to the filter centre).  16 dwords per ray: (ph0..3, h8) twice, (pm0..3, m8a), (M E, L E); lane (g, c) needs
+// dwords 4 g .. 4 g + 3 of the rays of lanes (G, c): the two-stage transpose of build_ray_operands16 on 4-dword pieces.
+__device__ __forceinline__ void build_ray_operands32(float ox, float oy, float oz, float dx, float dy, float dz, bool alive, RayOperands32& R) {
+    const float od = dotf(ox, oy, oz, dx, dy, dz), oo = dotf(ox, oy, oz, ox, oy, oz);
+    float x[9] = { dx * dx, dy * dy, dz * dz, 2.0f * dx * dy, 2.0f * dx * dz, 2.0f * dy * dz,
+                   2.0f * (ox - od * dx), 2.0f * (oy - od * dy), 2.0f * (oz - od * dz) };
+    float e = alive ? od * od - oo * (1.0f - kFilterEps32) : -3e30f;
+    uint32_t ph[4], pm[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ph[i] = pk_bf16(x[2 * i], x[2 * i + 1]); x[2 * i] -= pk_lo(ph[i]); x[2 * i + 1] -= pk_hi(ph[i]); }
+    const uint32_t h8 = pk_bf16(x[8], 1.0f);
+    x[8] -= pk_lo(h8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) pm[i] = pk_bf16(x[2 * i], x[2 * i + 1]);
+    const uint32_t m8a = pk_bf16(x[8], e);                          // (M x_8, H E)
+    e -= pk_hi(m8a);
+    const uint32_t em = pk_bf16(e, 0.0f);                           // M E
+    const uint32_t eml = pk_bf16(e, e - pk_lo(em));                 // (M E, L E)
+    const uint32_t D[16] = { ph[0], ph[1], ph[2], ph[3], h8, ph[0], ph[1], ph[2], ph[3], h8, pm[0], pm[1], pm[2], pm[3], m8a, eml };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t x0, y0, x1, y1, s0e, s0o, s1e, s1o;
+        swap32(D[i], D[8 + i], x0, y0);                             // what goes to lane groups 0 | 2
+        swap32(D[4 + i], D[12 + i], x1, y1);                        // 1 | 3
+        swap16(x0, x1, s0e, s0o);
+        swap16(y0, y1, s1e, s1o);
+        R.b[0][i] = s0e; R.b[1][i] = s0o; R.b[2][i] = s1e; R.b[3][i] = s1o;
+    }
+}
+// The scan: per row block 2 ds_read_b128, 8 MFMAs, 32 v_alignbit; candidate words exactly as mfma16_scan_tile's.
+template <uint32_t STRIDE = kMB>
+__device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands32& R, uint32_t* bm, uint32_t lane) {
+    uint32_t nz = 0;
+    if (n_blocks == 0) return nz;
+    const u32x4* fr = s_frag + lane;
+    u32x4 a0 = fr[0], a1 = fr[64];                                  // rows 0..15 | 16..31 of the block
+    auto mm = [](const u32x4& a, const u32x4& b) {
+        const f32x4v zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), zero, 0, 0, 0);
+    };
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {
+        uint32_t* bm0 = bm + b0 * STRIDE;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            if (b0 + u >= n_blocks) break;
+            const f32x4v d13 = mm(a1, R.b[3]), d03 = mm(a0, R.b[3]), d12 = mm(a1, R.b[2]), d02 = mm(a0, R.b[2]);
+            const f32x4v d11 = mm(a1, R.b[1]), d01 = mm(a0, R.b[1]), d10 = mm(a1, R.b[0]), d00 = mm(a0, R.b[0]);
+            if (b0 + u + 1 < n_blocks) { const u32x4* fn = fr + (size_t)(b0 + u + 1) * 128; a0 = fn[0]; a1 = fn[64]; }
+            uint32_t n = 0xFFFFFFFFu;                               // bit 8 G + 4 h + j, shifted in from the top
+            const f32x4v* order[8] = { &d13, &d03, &d12, &d02, &d11, &d01, &d10, &d00 };
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int j = 3; j >= 0; j--) n = __builtin_amdgcn_alignbit(n, __float_as_uint((*order[k])[j]), 31);
+            bm0[u * STRIDE] = n;
+            asm("v_cmp_ne_u32_e32 vcc, -1, %1\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(nz) : "v"(n) : "vcc");
+        }
+    }
+    return nz;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Exact tests at full lane utilisation: the candidates of a wave's 64 rays are compacted into a (ray lane, primitive) pair list
 // ------------------------------------------------------------------------------------------------------
 // A ray has few candidates but they cluster (a ray skimming a tessellated wall meets dozens of bounding spheres in one tile while its
@@ -569,24 +667,34 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
         LaneRay ray = { P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, REF && P.depth == 0 };
         float ux = ray.dx, uy = ray.dy, uz = ray.dz;                            // what the filter sees: always a unit direction
         if (REF && ray.literal) { const float inv = 1.0f / __builtin_sqrtf(dot3(ux, uy, uz, ux, uy, uz)); ux = ux * inv; uy = uy * inv; uz = uz * inv; }
-        RayOperands16 R;
-        build_ray_operands16(ray.ox, ray.oy, ray.oz, ux, uy, uz, alive, R);
+        RayOperands16 R;                                                        // faces: K = 64
+        RayOperands32 R32;                                                      // spheres: K = 32, coordinates about the filter centre
+        if (HAS_TRI) build_ray_operands16(ray.ox, ray.oy, ray.oz, ux, uy, uz, alive, R);
+        if (HAS_SPH && !HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);
         keys[lane] = kKeyNone;
         uint32_t n_pairs = 0;
 
-        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto&& test) {
+        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto&& test) {
+            constexpr bool K32 = decltype(k32)::value;                          // spheres: 2 operand fragments (2 KiB) per row block, else 4
+            constexpr uint32_t kVec = K32 ? 128u : 256u;
+            constexpr uint32_t kTile = K32 ? 32u : 16u;                         // row blocks per 64-KiB tile: half as many barriers per block for K = 32
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
-            for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
-                const uint32_t nb = min(16u, total_blocks - b0);
+            for (uint32_t b0 = 0; b0 < total_blocks; b0 += kTile) {
+                const uint32_t nb = min(kTile, total_blocks - b0);
                 RT3_PHASE(pt_rest)
-                fill_tile(s_frag, frags + (size_t)b0 * 256, nb * 256, tid);
+                fill_tile(s_frag, frags + (size_t)b0 * kVec, nb * kVec, tid);
                 RT3_PHASE(pt_fill)
                 if (live == 0ull) continue;                                     // a wave without rays (the tail of a launch) only keeps the barriers
-                const uint32_t nz = mfma16_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-                RT3_PHASE(pt_scan)
-                push_pairs16(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
-                RT3_PHASE(pt_push)
-                mfmas += nb * 16ull;
+                for (uint32_t h0 = 0; h0 < nb; h0 += 16) {                      // the candidate words hold 16 row blocks: scan and push in halves
+                    const uint32_t hb = min(16u, nb - h0);
+                    uint32_t nz;
+                    if constexpr (K32) nz = mfma32k_scan_tile(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane);
+                    else nz = mfma16_scan_tile(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
+                    RT3_PHASE(pt_scan)
+                    push_pairs16(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
+                    RT3_PHASE(pt_push)
+                    mfmas += hb * (K32 ? 8ull : 16ull);
+                }
             }
             test_all(lane, pairs, n_pairs, test);                               // what is left at the end of the pass
             RT3_PHASE(pt_test)
@@ -605,9 +713,10 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
                 if (!face_inside(n, p1, p2, p3, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t)) return;
                 if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
             };
-            pass(tri_frags, A.n_tri, test);
+            pass(tri_frags, A.n_tri, std::false_type(), test);
         }
         if (HAS_SPH) {
+            if (HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);   // (after the faces' pass: their operands are dead)
             auto test = [&](uint32_t pair, bool valid) {
                 const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
                 const LaneRay r = fetch_ray<false>(ray, src);
@@ -616,7 +725,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
                 float t;
                 if (sphere_root(A.sph[j], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 1u, j));
             };
-            pass(sph_frags, A.n_sph, test);
+            pass(sph_frags, A.n_sph, std::true_type(), test);
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t kind, ibest;
