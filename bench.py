@@ -142,8 +142,9 @@ def counters_from_profile(fingerprint):
         return None, "%s lacks FETCH_SIZE / WRITE_SIZE" % PMC_PROFILE, None
 
 
-def executed(st, prims_per_cast):
-    """Executed-work figures of the last render on a context, from the kernel's own counters and its HIP-event time."""
+def executed(st, k_slots=64):
+    """Executed-work figures of the last render on a context, from the kernel's own counters and its HIP-event time.
+    k_slots: K of the filter contraction the kernel ran (64, or 32 for the sphere pass of the tiled kernels): 2 K FLOP per test."""
     k_ms = st.trace_ms
     tf = st.mfma_instructions * float(st.mfma_flop_per_instruction) / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     d = {"kernel_ms": round(k_ms, 3), "launches": st.launches, "ray_casts": int(st.ray_casts), "prim_tests": int(st.prim_tests),
@@ -151,7 +152,12 @@ def executed(st, prims_per_cast):
          "mfma_tflops": round(tf, 1), "mfma_frac_of_bf16_peak": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)}
     if st.mfma_instructions:
         # the matrix cores work per wave whatever the number of live lanes: tests needed / tests the issued MFMAs evaluated
-        d["lane_efficiency"] = round(st.prim_tests / (st.mfma_instructions * st.mfma_flop_per_instruction / 32768.0 / 8.0 * 32 * 64), 4)
+        d["lane_efficiency"] = round(st.prim_tests * 2.0 * k_slots / (st.mfma_instructions * float(st.mfma_flop_per_instruction)), 4)
+        d["filter_k"] = k_slots
+    if k_slots != 64 and k_ms > 0:
+        # the same test rate priced in the K = 64 form of round 1 / the other kernels: an equivalence figure for comparisons across rounds,
+        # not work this kernel executes (it runs half the matrix work per test, which is why it is faster)
+        d["k64_equivalent_frac_of_bf16_peak"] = round(st.prim_tests * 128.0 / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
     if st.exact_tests:
         d["exact_tests_per_cast"] = round(st.exact_tests / max(1, st.ray_casts), 2)
     return d
@@ -163,13 +169,13 @@ def extra_workloads(rt3, r, np):
     empty_f, empty_v = np.zeros(0, rt3.GFACE), np.zeros((0, 4), np.float32)
     no_sph = (np.zeros((0, 4), np.float32), np.zeros(0, rt3.MATERIAL))
 
-    def path(name, cam, params, kernel):
+    def path(name, cam, params, kernel, k_slots=64):
         r.render_path(cam.c, params)                                     # warm-up: allocations, occupancy query
         r.render_path(cam.c, params)
         st = r.stats()
         d = {"workload": name, "kernel": kernel, "samples": int(st.samples), "ms": round(st.total_ms, 3),
              "msamples_per_s": round(st.samples / st.total_ms / 1e3, 2)}
-        d.update(executed(st, 0))
+        d.update(executed(st, k_slots))
         out.append(d)
 
     # Mode R: the reference's own render (SequentialRenderer::render) of its built-in scene, the one workload with a reference CPU time
@@ -203,14 +209,15 @@ def extra_workloads(rt3, r, np):
     r.set_spheres(cr, mats)
     cam = rt3.Camera().look_at(1920, 1080, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
     path("config 4: 100 000 spheres, 1920x1080, 16 of 256 spp, depth 50", cam,
-         rt3.make_params(1920, 1080, spp=16, max_depth=50, flags=rt3.FLAG_GAMMA2), "k_trace_mfma_tiled<spheres> (v_mfma_f32_16x16x32_bf16)")
+         rt3.make_params(1920, 1080, spp=16, max_depth=50, flags=rt3.FLAG_GAMMA2),
+         "k_trace_mfma_tiled<spheres> (K = 32 filter: one v_mfma_f32_16x16x32_bf16 per 16 x 16 tests)", k_slots=32)
     # config 5: Cornell-style box, 47 106 triangles, emissive quad
     faces, verts, fm = rt3.scene_cornell(64)
     r.set_spheres(*no_sph)
     r.set_mesh(faces, verts, fm)
     cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
     path("config 5: Cornell-style box, %d triangles, emissive quad, 1024x1024, 32 of 2048 spp, depth 50" % len(faces), cam,
-         rt3.make_params(1024, 1024, spp=32, max_depth=50, flags=rt3.FLAG_GAMMA2 | rt3.FLAG_BLACK_BACKGROUND), "k_trace_mfma_tiled<faces> (v_mfma_f32_16x16x32_bf16)")
+         rt3.make_params(1024, 1024, spp=32, max_depth=50, flags=rt3.FLAG_GAMMA2 | rt3.FLAG_BLACK_BACKGROUND), "k_trace_mfma_tiled<faces> (K = 64 filter: two v_mfma_f32_16x16x32_bf16 per 16 x 16 tests)")
     r.set_mesh(empty_f, empty_v)
     return out
 

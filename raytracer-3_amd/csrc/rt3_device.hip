@@ -655,8 +655,8 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     } else if (use_mfma) {
         tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
                         : k_trace_mfma_tiled<false, true, false>;
-        lds = kTiledLdsBytes;
-        block = kMB;
+        lds = kTraceTiledLdsBytes;
+        block = kTB;
         kptr = (const void*)tiled;
     } else {
         lds = sph_lds ? (size_t)ctx->n_sph * sizeof(float4) : 0;
@@ -688,7 +688,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
         RT3_HIP(hipEventRecord(a, stream));
         if (mfma_single) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
-        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag32);
+        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kTB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag32);
         else hipLaunchKernelGGL(plain, dim3(grid), dim3(kBlock), lds, stream, A);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipEventRecord(b, stream));

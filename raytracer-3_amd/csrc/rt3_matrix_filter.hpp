@@ -622,24 +622,30 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
 // workgroup move through the tiles together (two barriers per tile); candidates go through the pair list above, the exact tests
 // gather their records from global memory, all 64 lanes at a time.
 // REF: RT3_FLAG_REFERENCE_PRIMARY (camera at the origin, no lens: checked by the host).
-constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;
+#ifndef RT3_TILED_TB
+#define RT3_TILED_TB 1024
+#endif
+constexpr uint32_t kTB = RT3_TILED_TB;                              // threads per workgroup of k_trace_mfma_tiled; the fragment tile is kTB * 64 bytes
+constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;     // k_mode_r_mfma
+constexpr size_t kTraceTiledLdsBytes = (size_t)kTB * (64 + 16 * 4 + 8) + (size_t)(kTB / 64) * kPairCap * 4;
 // One tile of fragments through the workgroup: [barrier] loads -> LDS stores [barrier].
+template <uint32_t TB = kMB>
 __device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict__ src, uint32_t n_vec, uint32_t tid) {
     __syncthreads();                                                // every wave is done with the previous tile
     u32x4 v[4];
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) v[i] = src[min(tid + i * kMB, n_vec - 1u)];       // unconditional: four loads in flight, no branches
+    for (uint32_t i = 0; i < 4; i++) v[i] = src[min(tid + i * TB, n_vec - 1u)];       // unconditional: four loads in flight, no branches
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) { const uint32_t k = tid + i * kMB; if (k < n_vec) s_frag[k] = v[i]; }
+    for (uint32_t i = 0; i < 4; i++) { const uint32_t k = tid + i * TB; if (k < n_vec) s_frag[k] = v[i]; }
     __syncthreads();
 }
 template <bool HAS_TRI, bool HAS_SPH, bool REF>
-__global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
+__global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     extern __shared__ u32x4 lds_dyn[];
-    u32x4* s_frag = lds_dyn;                                                   // [16][4][64]
-    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);           // [16][kMB] candidate words
-    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kMB);   // [kMB] nearest hit of every lane's ray
-    uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kMB);              // [16 waves][kPairCap]
+    u32x4* s_frag = lds_dyn;                                                   // kTB * 4 vectors: [16][4][64] at 1024 threads
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + kTB * 4);            // [16][kTB] candidate words
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kTB);   // [kTB] nearest hit of every lane's ray
+    uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kTB);              // [waves][kPairCap]
     const uint32_t tid = threadIdx.x, lane = lane_id();
     uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
     unsigned long long* keys = s_key + (tid & ~63u);                           // this wave's 64 records
@@ -677,21 +683,21 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma_tiled(const TraceArgs A, con
         auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto&& test) {
             constexpr bool K32 = decltype(k32)::value;                          // spheres: 2 operand fragments (2 KiB) per row block, else 4
             constexpr uint32_t kVec = K32 ? 128u : 256u;
-            constexpr uint32_t kTile = K32 ? 32u : 16u;                         // row blocks per 64-KiB tile: half as many barriers per block for K = 32
+            constexpr uint32_t kTile = kTB * 4u / kVec;                         // row blocks per tile (64 KiB at 1024 threads): 32 | 16
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
             for (uint32_t b0 = 0; b0 < total_blocks; b0 += kTile) {
                 const uint32_t nb = min(kTile, total_blocks - b0);
                 RT3_PHASE(pt_rest)
-                fill_tile(s_frag, frags + (size_t)b0 * kVec, nb * kVec, tid);
+                fill_tile<kTB>(s_frag, frags + (size_t)b0 * kVec, nb * kVec, tid);
                 RT3_PHASE(pt_fill)
                 if (live == 0ull) continue;                                     // a wave without rays (the tail of a launch) only keeps the barriers
                 for (uint32_t h0 = 0; h0 < nb; h0 += 16) {                      // the candidate words hold 16 row blocks: scan and push in halves
                     const uint32_t hb = min(16u, nb - h0);
                     uint32_t nz;
-                    if constexpr (K32) nz = mfma32k_scan_tile(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane);
-                    else nz = mfma16_scan_tile(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
+                    if constexpr (K32) nz = mfma32k_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane);
+                    else nz = mfma16_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
                     RT3_PHASE(pt_scan)
-                    push_pairs16(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
+                    push_pairs16<kTB>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
                     RT3_PHASE(pt_push)
                     mfmas += hb * (K32 ? 8ull : 16ull);
                 }

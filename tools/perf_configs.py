@@ -16,7 +16,7 @@ quick = "--quick" in sys.argv
 only = [a for a in sys.argv[1:] if a.isdigit()]                      # e.g. `4 5`: just those configs
 
 
-def run_path(r, name, cam, params, reps=1):
+def run_path(r, name, cam, params, reps=1, k_slots=64):           # k_slots: K of the filter the kernel runs (2 K FLOP per test)
     r.render_path(cam.c, params)                       # warm-up (allocations)
     best = None
     for _ in range(reps):
@@ -30,7 +30,7 @@ def run_path(r, name, cam, params, reps=1):
                    mfma=st.mfma_instructions, mfma_frac_of_2500TF=round(st.mfma_instructions * float(st.mfma_flop_per_instruction) / (st.trace_ms * 1e-3) / 2.5e15, 4),
                    exact_per_cast=round(st.exact_tests / max(1, st.ray_casts), 2),
                    # MFMA work is per wave whatever the number of live lanes: tests the matrix cores evaluated / tests that were needed
-                   lane_efficiency=round(st.prim_tests / max(1.0, st.mfma_instructions * st.mfma_flop_per_instruction / 32768.0 / 8.0 * 32 * 64), 4))
+                   lane_efficiency=round(st.prim_tests * 2.0 * k_slots / max(1.0, st.mfma_instructions * float(st.mfma_flop_per_instruction)), 4))
         if best is None or row["total_ms"] < best["total_ms"]:
             best = row
     print(json.dumps(best), flush=True)
@@ -71,7 +71,7 @@ def main():
     cr, mats = rt3.scene_stress(100000, 43)
     r.set_spheres(cr, mats)
     cam = rt3.Camera().look_at(1920, 1080, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
-    run_path(r, "4: 100k spheres 1920x1080x%d d50" % (8 if quick else 256), cam, rt3.make_params(1920, 1080, spp=8 if quick else 256, max_depth=50, flags=1))
+    run_path(r, "4: 100k spheres 1920x1080x%d d50" % (8 if quick else 256), cam, rt3.make_params(1920, 1080, spp=8 if quick else 256, max_depth=50, flags=1), k_slots=32)
     # config 5
     faces, verts, fm = rt3.scene_cornell(64)
     r.set_spheres(np.zeros((0, 4), np.float32), np.zeros(0, rt3.MATERIAL))
@@ -88,7 +88,7 @@ def tiled_only(r):
         r.set_mesh(np.zeros(0, rt3.GFACE), np.zeros((0, 4), np.float32))
         r.set_spheres(cr, mats)
         cam = rt3.Camera().look_at(1920, 1080, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
-        run_path(r, "4: 100k spheres 1920x1080x%d d50" % spp, cam, rt3.make_params(1920, 1080, spp=spp, max_depth=50, flags=1))
+        run_path(r, "4: 100k spheres 1920x1080x%d d50" % spp, cam, rt3.make_params(1920, 1080, spp=spp, max_depth=50, flags=1), k_slots=32)
     if "5" in only:
         faces, verts, fm = rt3.scene_cornell(64)
         r.set_spheres(np.zeros((0, 4), np.float32), np.zeros(0, rt3.MATERIAL))
