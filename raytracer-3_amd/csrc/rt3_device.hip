@@ -57,7 +57,7 @@ struct rt3_ctx {
     rt3_material* d_face_mats_in = nullptr; uint32_t* d_error = nullptr;
     // spheres
     uint32_t n_sph = 0;
-    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
+    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; float tri_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t* d_box = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
     // work buffers
     Rgb* d_rad = nullptr; size_t rad_entries = 0;
@@ -190,16 +190,18 @@ float4 pack_material(const rt3_material& m) {
 
 // Sphere-side operand fragments of the matrix filter: [row block of 32 spheres][4 MFMA operands][64 lanes] x 8 bf16.
 // Lane l holds, for operand row (l & 31) — sphere b of the block sits in row frag_row_of(b) — K elements 8 (l >> 5) .. +7;
-// padding rows can never be candidates.
-std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n) {
+// padding rows can never be candidates.  Coordinates relative to `centre` (sphere_filter_centre: it keeps |C|^2 + |o|^2, and with it the
+// filter's margin, small for a scene that is not built around the world origin).
+std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n, const float centre[3]) {
     const uint32_t blocks = (n + 31u) / 32u;
     std::vector<uint32_t> out((size_t)blocks * 4 * 64 * 4, 0u);
     for (uint32_t j = 0; j < blocks * 32; j++) {
         uint32_t fr[4][2][4];
         if (j < n) {
             const float* s = center_radius + 4 * (size_t)j;
-            const double c2 = (double)s[0] * s[0] + (double)s[1] * s[1] + (double)s[2] * s[2], r2 = (double)s[3] * s[3];
-            bound_frag_row(s[0], s[1], s[2], filter_kj(c2, r2), fr);
+            const float cx = (float)((double)s[0] - centre[0]), cy = (float)((double)s[1] - centre[1]), cz = (float)((double)s[2] - centre[2]);
+            const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz, r2 = (double)s[3] * s[3];
+            bound_frag_row(cx, cy, cz, filter_kj(c2, r2), fr);
         } else bound_frag_row(0.0f, 0.0f, 0.0f, kNeverCandidate, fr);
         for (int q = 0; q < 4; q++)
             for (int hh = 0; hh < 2; hh++)
@@ -209,7 +211,7 @@ std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n)
 }
 
 // The same spheres as fragments of the K = 32 form of the tiled kernels (rt3_matrix_filter.hpp): [row block][h][lane 16 g + c] x 8 bf16,
-// coordinates relative to `centre` (the centroid: it keeps |C|^2, and with it the filter's margin, small).
+// coordinates relative to the same centre.
 std::vector<uint32_t> build_sphere_frags32(const float* center_radius, uint32_t n, const float centre[3]) {
     const uint32_t blocks = (n + 31u) / 32u;
     std::vector<uint32_t> out((size_t)blocks * 2 * 64 * 4, 0u);
@@ -224,6 +226,26 @@ std::vector<uint32_t> build_sphere_frags32(const float* center_radius, uint32_t 
         for (uint32_t g = 0; g < 4; g++) std::memcpy(&out[frag32_index(j / 32, j % 32, g) * 4], fr[g], 16);
     }
     return out;
+}
+
+// The centre of the spheres' filter coordinates: the centroid of the centres weighted by 1 / (r^2 + 0.001 mean r^2) — the point that
+// minimises the sum over the spheres of margin / r^2, the relative growth of their candidate cross-sections (a ground sphere of radius
+// 1000 does not pull it away from the spheres that matter).  (0, 0, 0) if that is not a finite point.
+void sphere_filter_centre(const float* center_radius, uint32_t n, float out[3]) {
+    out[0] = out[1] = out[2] = 0.0f;
+    double mean_r2 = 0.0;
+    for (uint32_t i = 0; i < n; i++) mean_r2 += (double)center_radius[4 * (size_t)i + 3] * center_radius[4 * (size_t)i + 3];
+    mean_r2 = n ? mean_r2 / n : 0.0;
+    double c[3] = { 0.0, 0.0, 0.0 }, wsum = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        const float* s = center_radius + 4 * (size_t)i;
+        const double w = 1.0 / ((double)s[3] * s[3] + 1e-3 * mean_r2);
+        for (int a = 0; a < 3; a++) c[a] += w * s[a];
+        wsum += w;
+    }
+    if (!(wsum > 0.0) || !std::isfinite(wsum)) return;
+    const float f[3] = { (float)(c[0] / wsum), (float)(c[1] / wsum), (float)(c[2] / wsum) };
+    if (std::isfinite(f[0]) && std::isfinite(f[1]) && std::isfinite(f[2])) { out[0] = f[0]; out[1] = f[1]; out[2] = f[2]; }
 }
 
 bool row_owned(const rt3_params* p, uint32_t y) {
@@ -303,7 +325,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
-                     ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts };
+                     ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -397,13 +419,25 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
         RT3_HIP(hipMalloc((void**)&ctx->d_face_mats_in, (size_t)n * sizeof(rt3_material)));
         RT3_HIP(hipMemcpyAsync(ctx->d_face_mats_in, face_materials, (size_t)n * sizeof(rt3_material), hipMemcpyHostToDevice, ctx->stream));
     }
+    // the box of the vertices: its centre is what the faces' filter coordinates are taken about (k_commit_mesh and the ray side agree on it
+    // through box_centre())
+    if (!ctx->d_box) RT3_HIP(hipMalloc((void**)&ctx->d_box, 6 * sizeof(uint32_t)));
+    RT3_HIP(hipMemsetAsync(ctx->d_box, 0xFF, 3 * sizeof(uint32_t), ctx->stream));
+    RT3_HIP(hipMemsetAsync(ctx->d_box + 3, 0, 3 * sizeof(uint32_t), ctx->stream));
+    if (ctx->cap_verts) {
+        hipLaunchKernelGGL(k_vertex_box, dim3(std::min<uint32_t>(256u, (ctx->cap_verts + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                           (const float4*)ctx->d_verts, ctx->cap_verts, ctx->d_box);
+        RT3_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_commit_mesh, dim3((n_frag_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, ctx->d_gfaces, ctx->d_verts, n, n_pad,
                        ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
-                       ctx->d_tri_frag, n_frag_rows);
+                       ctx->d_tri_frag, n_frag_rows, (const uint32_t*)ctx->d_box);
     RT3_HIP(hipGetLastError());
-    uint32_t err = 0;
+    uint32_t err = 0, box[6];
     RT3_HIP(hipMemcpyAsync(&err, ctx->d_error, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT3_HIP(hipMemcpyAsync(box, ctx->d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
     RT3_HIP(hipStreamSynchronize(ctx->stream));
+    box_centre(box, ctx->tri_centre);
     if (err) return fail(ctx, RT3_E_ARG, "a face references a vertex out of range");
     ctx->n_faces = n;
     return 0;
@@ -445,12 +479,8 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
         kind[i] = materials[i].kind;
     }
     int rc;
-    if ((rc = upload(ctx, &ctx->d_sph_frag, build_sphere_frags(center_radius, n)))) return rc;        // k_trace_mfma (32x32x16 form)
-    double c0[3] = { 0.0, 0.0, 0.0 };
-    for (uint32_t i = 0; i < n; i++) for (int a = 0; a < 3; a++) c0[a] += center_radius[4 * (size_t)i + a];
-    for (int a = 0; a < 3; a++) ctx->sph_centre[a] = n ? (float)(c0[a] / n) : 0.0f;
-    if (!(std::isfinite(ctx->sph_centre[0]) && std::isfinite(ctx->sph_centre[1]) && std::isfinite(ctx->sph_centre[2])))
-        ctx->sph_centre[0] = ctx->sph_centre[1] = ctx->sph_centre[2] = 0.0f;
+    sphere_filter_centre(center_radius, n, ctx->sph_centre);
+    if ((rc = upload(ctx, &ctx->d_sph_frag, build_sphere_frags(center_radius, n, ctx->sph_centre)))) return rc;        // k_trace_mfma (32x32x16 form)
     if ((rc = upload(ctx, &ctx->d_sph_frag32, build_sphere_frags32(center_radius, n, ctx->sph_centre)))) return rc;    // tiled kernels (K = 32 form)
     if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
         (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
@@ -519,7 +549,8 @@ int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint3
     RT3_HIP(hipEventRecord(a, stream));
     if (use_mfma)
         hipLaunchKernelGGL(k_mode_r_mfma, dim3((npix + kMB - 1) / kMB), dim3(kMB), kTiledLdsBytes, stream,
-                           ctx->d_tri, (const u32x4*)ctx->d_tri_frag, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
+                           ctx->d_tri, (const u32x4*)ctx->d_tri_frag, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out,
+                           ctx->tri_centre[0], ctx->tri_centre[1], ctx->tri_centre[2]);
     else if (at_origin && !ctx->force_plain_mode_r)
         hipLaunchKernelGGL(k_mode_r_fast, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                            ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);
@@ -625,6 +656,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         return fail(ctx, RT3_E_DEVICE, "internal: magic-number division self-check failed");
     A.rad = ctx->d_rad; A.work_counter = ctx->d_work; A.cast_counter = ctx->d_casts;
     A.fcx = ctx->sph_centre[0]; A.fcy = ctx->sph_centre[1]; A.fcz = ctx->sph_centre[2];
+    A.tcx = ctx->tri_centre[0]; A.tcy = ctx->tri_centre[1]; A.tcz = ctx->tri_centre[2];
 
     // ---- which kernel
     //   brute         every ray against every primitive (debug switch / RT3_BRUTE=1; REFERENCE_PRIMARY with a camera off the origin or a lens)

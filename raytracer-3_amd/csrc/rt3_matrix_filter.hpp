@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
         iters++;
         const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
         RayOperands R;
-        build_ray_operands(ox, oy, oz, dx, dy, dz, alive, R);
+        build_ray_operands(ox - A.fcx, oy - A.fcy, oz - A.fcz, dx, dy, dz, alive, R);      // the fragments are about (fcx, fcy, fcz)
 
         // nearest hit: exact evaluation of queued candidates (ties: lower sphere index, as the sequential loop)
         float tbest = __builtin_inff();
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
         if (REF && ray.literal) { const float inv = 1.0f / __builtin_sqrtf(dot3(ux, uy, uz, ux, uy, uz)); ux = ux * inv; uy = uy * inv; uz = uz * inv; }
         RayOperands16 R;                                                        // faces: K = 64
         RayOperands32 R32;                                                      // spheres: K = 32, coordinates about the filter centre
-        if (HAS_TRI) build_ray_operands16(ray.ox, ray.oy, ray.oz, ux, uy, uz, alive, R);
+        if (HAS_TRI) build_ray_operands16(ray.ox - A.tcx, ray.oy - A.tcy, ray.oz - A.tcz, ux, uy, uz, alive, R);
         if (HAS_SPH && !HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);
         keys[lane] = kKeyNone;
         uint32_t n_pairs = 0;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
 // runs on the candidates through the pair list; "t >= min_t rejects" of :71 == the lowest index wins ties == the key order.
 __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ tri, const u32x4* __restrict__ tri_frags,
                                                     const float4* __restrict__ face_rgb, uint32_t n_faces, CamDev cam,
-                                                    uint32_t width, uint32_t height, uint32_t* __restrict__ out) {
+                                                    uint32_t width, uint32_t height, uint32_t* __restrict__ out, float tcx, float tcy, float tcz) {
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + 16 * 256);
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
     const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
     const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));     // unit direction for the filter only
     RayOperands16 R;
-    build_ray_operands16(ox, oy, oz, dx * inv, dy * inv, dz * inv, valid_px, R);
+    build_ray_operands16(ox - tcx, oy - tcy, oz - tcz, dx * inv, dy * inv, dz * inv, valid_px, R);     // the fragments are about (tcx, tcy, tcz)
     const LaneRay ray = { ox, oy, oz, dx, dy, dz, true };
     keys[lane] = kKeyNone;
     uint32_t n_pairs = 0;

@@ -64,11 +64,38 @@ __global__ void k_prerender_sphere_faces(SphereGen s, rt3_gface* __restrict__ fa
 
 // De-indexes the merged GFace[] / vec4[] into what the render kernels read: 4 float4 per face (n + plane distance, p1, p2,
 // p3), the bounding sphere of §5.1, the material.  Entries [n_faces, n_pad) of `bound` become never-hit records.
+// The box of the finite vertex coordinates, as order-preserving integers: box[0..2] = min x, y, z; box[3..5] = max (start: ~0 / 0).
+__host__ __device__ inline uint32_t ordered_bits(float f) { const uint32_t b = __builtin_bit_cast(uint32_t, f); return (b >> 31) ? ~b : (b | 0x80000000u); }
+__host__ __device__ inline float ordered_float(uint32_t k) { return __builtin_bit_cast(float, (k >> 31) ? (k & 0x7FFFFFFFu) : ~k); }
+// Centre of that box (0 for an empty or unusable one): what the faces' filter coordinates are taken about.
+__host__ __device__ inline void box_centre(const uint32_t box[6], float out[3]) {
+    for (int a = 0; a < 3; a++) {
+        const float lo = ordered_float(box[a]), hi = ordered_float(box[3 + a]);
+        const float c = (float)(0.5 * ((double)lo + (double)hi));
+        out[a] = (box[a] <= box[3 + a] && c - c == 0.0f) ? c : 0.0f;
+    }
+}
+__global__ void k_vertex_box(const float4* __restrict__ verts, uint32_t n_verts, uint32_t* __restrict__ box) {
+    float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_verts; i += gridDim.x * blockDim.x) {
+        const float4 v = verts[i];
+        const float c[3] = { v.x, v.y, v.z };
+        for (int a = 0; a < 3; a++)
+            if (c[a] - c[a] == 0.0f) { lo[a] = fminf(lo[a], c[a]); hi[a] = fmaxf(hi[a], c[a]); }      // finite values only
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+        if ((threadIdx.x & 63u) == 0u && lo[a] <= hi[a]) { atomicMin(box + a, ordered_bits(lo[a])); atomicMax(box + 3 + a, ordered_bits(hi[a])); }
+    }
+}
+
 __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4* __restrict__ verts, uint32_t n_faces, uint32_t n_pad,
                               uint32_t n_verts, const rt3_material* __restrict__ mats, float4* __restrict__ tri, float4* __restrict__ bound,
                               float4* __restrict__ mat, uint32_t* __restrict__ kind, uint32_t* __restrict__ error_flag,
-                              u32x4* __restrict__ frag, uint32_t n_frag_rows) {
+                              u32x4* __restrict__ frag, uint32_t n_frag_rows, const uint32_t* __restrict__ box) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float centre[3];
+    box_centre(box, centre);
     // matrix-filter fragments (16x16x32 form): row i of block i/32, both K halves, all four lane groups (padding rows: never candidates)
     auto write_frag = [&](float cx, float cy, float cz, float kj) {
         if (i >= n_frag_rows) return;
@@ -121,7 +148,8 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
     if (always) r2f = 3e38f;                                        // finite: the VALU scan's h^2 - c + 1e-5 c must stay a number
     bound[i] = make_float4((float)cx, (float)cy, (float)cz, r2f);
     {
-        const float fx = (float)cx, fy = (float)cy, fz = (float)cz;
+        // the filter works in coordinates about the centre of the vertices' box (the VALU scan's `bound` stays in world coordinates)
+        const float fx = (float)(cx - (double)centre[0]), fy = (float)(cy - (double)centre[1]), fz = (float)(cz - (double)centre[2]);
         const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
         write_frag(fx, fy, fz, always ? kAlwaysCandidate : filter_kj(c2, (double)r2f));
     }

@@ -31,4 +31,5 @@ else:
     p = rt3.make_params(1024, 1024, spp=spp, max_depth=50, flags=3)
 r.render_path(cam.c, p)
 st = r.stats()
-print("config %s spp %d: trace %.3f ms, %d casts, %d mfma" % (which, spp, st.trace_ms, st.ray_casts, st.mfma_instructions))
+print("config %s spp %d: trace %.3f ms, %d casts, %d mfma, %.2f exact tests per cast" % (which, spp, st.trace_ms, st.ray_casts, st.mfma_instructions,
+                                                                                       st.exact_tests / max(1, st.ray_casts)))
