@@ -57,7 +57,7 @@ struct rt3_ctx {
     rt3_material* d_face_mats_in = nullptr; uint32_t* d_error = nullptr;
     // spheres
     uint32_t n_sph = 0;
-    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; float tri_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t* d_box = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
+    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; float tri_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t* d_box = nullptr; uint32_t* d_tri_frag_r = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
     // work buffers
     Rgb* d_rad = nullptr; size_t rad_entries = 0;
@@ -228,24 +228,21 @@ std::vector<uint32_t> build_sphere_frags32(const float* center_radius, uint32_t 
     return out;
 }
 
-// The centre of the spheres' filter coordinates: the centroid of the centres weighted by 1 / (r^2 + 0.001 mean r^2) — the point that
-// minimises the sum over the spheres of margin / r^2, the relative growth of their candidate cross-sections (a ground sphere of radius
-// 1000 does not pull it away from the spheres that matter).  (0, 0, 0) if that is not a finite point.
+// The centre of the spheres' filter coordinates: the component-wise median of the centres — the middle of where the spheres are,
+// whatever a few far or huge ones do (the book scene's ground sphere, centre y = -1000, moves the mean by two units and the median not at
+// all; weights of 1 / r^2, the minimiser of the sum of margin / r^2, follow the few smallest spheres instead: 9 % more exact tests on the
+// 100 000-sphere scene).  Non-finite coordinates are skipped; (0, 0, 0) without any.
 void sphere_filter_centre(const float* center_radius, uint32_t n, float out[3]) {
-    out[0] = out[1] = out[2] = 0.0f;
-    double mean_r2 = 0.0;
-    for (uint32_t i = 0; i < n; i++) mean_r2 += (double)center_radius[4 * (size_t)i + 3] * center_radius[4 * (size_t)i + 3];
-    mean_r2 = n ? mean_r2 / n : 0.0;
-    double c[3] = { 0.0, 0.0, 0.0 }, wsum = 0.0;
-    for (uint32_t i = 0; i < n; i++) {
-        const float* s = center_radius + 4 * (size_t)i;
-        const double w = 1.0 / ((double)s[3] * s[3] + 1e-3 * mean_r2);
-        for (int a = 0; a < 3; a++) c[a] += w * s[a];
-        wsum += w;
+    std::vector<float> v;
+    v.reserve(n);
+    for (int a = 0; a < 3; a++) {
+        v.clear();
+        for (uint32_t i = 0; i < n; i++) { const float c = center_radius[4 * (size_t)i + a]; if (std::isfinite(c)) v.push_back(c); }
+        out[a] = 0.0f;
+        if (v.empty()) continue;
+        std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+        out[a] = v[v.size() / 2];
     }
-    if (!(wsum > 0.0) || !std::isfinite(wsum)) return;
-    const float f[3] = { (float)(c[0] / wsum), (float)(c[1] / wsum), (float)(c[2] / wsum) };
-    if (std::isfinite(f[0]) && std::isfinite(f[1]) && std::isfinite(f[2])) { out[0] = f[0]; out[1] = f[1]; out[2] = f[2]; }
 }
 
 bool row_owned(const rt3_params* p, uint32_t y) {
@@ -325,7 +322,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
-                     ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box };
+                     ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -400,7 +397,8 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     if (!ctx) return RT3_E_ARG;
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
-    for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in })
+    for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in,
+                      (void**)&ctx->d_tri_frag_r })
         if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
     ctx->n_faces = 0;
     if (n == 0) return 0;
@@ -431,7 +429,7 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     }
     hipLaunchKernelGGL(k_commit_mesh, dim3((n_frag_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, ctx->d_gfaces, ctx->d_verts, n, n_pad,
                        ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
-                       ctx->d_tri_frag, n_frag_rows, (const uint32_t*)ctx->d_box);
+                       ctx->d_tri_frag, n_frag_rows, (const uint32_t*)ctx->d_box, 1.0f);
     RT3_HIP(hipGetLastError());
     uint32_t err = 0, box[6];
     RT3_HIP(hipMemcpyAsync(&err, ctx->d_error, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -544,13 +542,25 @@ int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint3
         int per_cu = 0;
         if ((rc = blocks_per_cu(ctx, (const void*)k_mode_r_mfma, kMB, kTiledLdsBytes, &per_cu))) return rc;
         if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_mode_r_mfma does not fit on a CU");
+        // Mode R's rays all start at the world origin, the path tracer's mostly ON the scene: the filter's margin eps (|C - c|^2 + r^2 +
+        // |o - c|^2) is smallest about the point half-way to the mesh here and about the mesh's own centre there.  Mode R therefore keeps
+        // fragments of its own, built at its first render after a commit by the same kernel (in that mode it writes nothing else).
+        if (!ctx->d_tri_frag_r) {
+            const uint32_t n = ctx->n_faces, n_pad = (n + 3u) / 4u * 4u, n_frag_rows = (n + 31u) / 32u * 32u;
+            RT3_HIP(hipMalloc((void**)&ctx->d_tri_frag_r, (size_t)n_frag_rows * 8 * sizeof(u32x4)));
+            hipLaunchKernelGGL(k_commit_mesh, dim3((n_frag_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, ctx->d_gfaces, ctx->d_verts, n, n_pad,
+                               ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
+                               (u32x4*)ctx->d_tri_frag_r, n_frag_rows, (const uint32_t*)ctx->d_box, 0.5f);
+            RT3_HIP(hipGetLastError());
+            RT3_HIP(hipStreamSynchronize(stream));                  // once per mesh: a later render may come on another stream
+        }
     }
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
     RT3_HIP(hipEventRecord(a, stream));
     if (use_mfma)
         hipLaunchKernelGGL(k_mode_r_mfma, dim3((npix + kMB - 1) / kMB), dim3(kMB), kTiledLdsBytes, stream,
-                           ctx->d_tri, (const u32x4*)ctx->d_tri_frag, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out,
-                           ctx->tri_centre[0], ctx->tri_centre[1], ctx->tri_centre[2]);
+                           ctx->d_tri, (const u32x4*)ctx->d_tri_frag_r, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out,
+                           0.5f * ctx->tri_centre[0], 0.5f * ctx->tri_centre[1], 0.5f * ctx->tri_centre[2]);
     else if (at_origin && !ctx->force_plain_mode_r)
         hipLaunchKernelGGL(k_mode_r_fast, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, stream,
                            ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->n_faces, cam_dev(cam), width, height, (uint32_t*)d_out);

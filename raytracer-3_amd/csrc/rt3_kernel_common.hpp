@@ -123,7 +123,7 @@ struct TraceArgs {
     uint32_t total;          // npix * samples in this batch
     Rgb* rad;                // per-sample radiance, [sample in batch][owned pixel], 12 B each
     // Centres the matrix filter's coordinates are taken about: the filter's margin is eps (|C|^2 + r^2 + |o|^2), so a scene far from the
-    // world origin would otherwise drown in candidates.  Spheres: their 1/r^2-weighted centroid; faces: the centre of the vertices' box.
+    // world origin would otherwise drown in candidates.  Spheres: the median of their centres; faces: the centre of the vertices' box.
     float fcx, fcy, fcz;     // spheres (k_trace_mfma, the K = 32 pass of k_trace_mfma_tiled)
     float tcx, tcy, tcz;     // faces (the K = 64 pass of k_trace_mfma_tiled)
     uint32_t* work_counter;

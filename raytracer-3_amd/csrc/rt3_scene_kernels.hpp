@@ -92,10 +92,12 @@ __global__ void k_vertex_box(const float4* __restrict__ verts, uint32_t n_verts,
 __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4* __restrict__ verts, uint32_t n_faces, uint32_t n_pad,
                               uint32_t n_verts, const rt3_material* __restrict__ mats, float4* __restrict__ tri, float4* __restrict__ bound,
                               float4* __restrict__ mat, uint32_t* __restrict__ kind, uint32_t* __restrict__ error_flag,
-                              u32x4* __restrict__ frag, uint32_t n_frag_rows, const uint32_t* __restrict__ box) {
+                              u32x4* __restrict__ frag, uint32_t n_frag_rows, const uint32_t* __restrict__ box, float centre_scale) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float centre[3];
-    box_centre(box, centre);
+    float centre[3];                                                // centre_scale: 1 for the path tracer; 0.5: Mode R's fragments (rt3_device.hip),
+    box_centre(box, centre);                                        //   a later launch that writes `frag` only
+    for (int a = 0; a < 3; a++) centre[a] *= centre_scale;
+    const bool all = centre_scale == 1.0f;
     // matrix-filter fragments (16x16x32 form): row i of block i/32, both K halves, all four lane groups (padding rows: never candidates)
     auto write_frag = [&](float cx, float cy, float cz, float kj) {
         if (i >= n_frag_rows) return;
@@ -106,14 +108,16 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
                 frag[frag16_index(i / 32, i % 32, q, g)] = u32x4{ fr[q][g][0], fr[q][g][1], fr[q][g][2], fr[q][g][3] };
     };
     if (i >= n_pad && i >= n_frag_rows) return;
-    if (i >= n_faces) { if (i < n_pad) bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
+    if (i >= n_faces) { if (all && i < n_pad) bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
     const rt3_gface f = faces[i];
-    if (f.v1 >= n_verts || f.v2 >= n_verts || f.v3 >= n_verts) { atomicOr(error_flag, 1u); bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
+    if (f.v1 >= n_verts || f.v2 >= n_verts || f.v3 >= n_verts) { if (all) { atomicOr(error_flag, 1u); bound[i] = kPadSphere; } write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
     const float4 p1 = verts[f.v1], p2 = verts[f.v2], p3 = verts[f.v3];
-    tri[4 * (size_t)i] = make_float4(f.normal[0], f.normal[1], f.normal[2], dot3(f.normal[0], f.normal[1], f.normal[2], p1.x, p1.y, p1.z));
-    tri[4 * (size_t)i + 1] = make_float4(p1.x, p1.y, p1.z, 0.0f);
-    tri[4 * (size_t)i + 2] = make_float4(p2.x, p2.y, p2.z, 0.0f);
-    tri[4 * (size_t)i + 3] = make_float4(p3.x, p3.y, p3.z, 0.0f);
+    if (all) {
+        tri[4 * (size_t)i] = make_float4(f.normal[0], f.normal[1], f.normal[2], dot3(f.normal[0], f.normal[1], f.normal[2], p1.x, p1.y, p1.z));
+        tri[4 * (size_t)i + 1] = make_float4(p1.x, p1.y, p1.z, 0.0f);
+        tri[4 * (size_t)i + 2] = make_float4(p2.x, p2.y, p2.z, 0.0f);
+        tri[4 * (size_t)i + 3] = make_float4(p3.x, p3.y, p3.z, 0.0f);
+    }
     // Bounding sphere of the region in which the REFERENCE'S test can report a hit (it must never be smaller: the exact test runs only
     // on the faces whose bound the ray's line meets).  That region is the triangle p1, p2', p3' in the plane through p1 normal to the
     // STORED normal, p' = p shifted along that normal (the three edge functions only see the projection along it) — the triangle
@@ -146,13 +150,14 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
     if ((double)r2f < r * r) r2f = __uint_as_float(__float_as_uint(r2f) + 1u);
     const bool always = degenerate || !(r2f < __builtin_inff());    // (NaN compares false)
     if (always) r2f = 3e38f;                                        // finite: the VALU scan's h^2 - c + 1e-5 c must stay a number
-    bound[i] = make_float4((float)cx, (float)cy, (float)cz, r2f);
+    if (all) bound[i] = make_float4((float)cx, (float)cy, (float)cz, r2f);
     {
         // the filter works in coordinates about the centre of the vertices' box (the VALU scan's `bound` stays in world coordinates)
         const float fx = (float)(cx - (double)centre[0]), fy = (float)(cy - (double)centre[1]), fz = (float)(cz - (double)centre[2]);
         const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
         write_frag(fx, fy, fz, always ? kAlwaysCandidate : filter_kj(c2, (double)r2f));
     }
+    if (!all) return;
     if (mats) {
         const rt3_material m = mats[i];
         if (m.kind == RT3_MAT_DIELECTRIC) {                         // same packing as pack_material() on the host

@@ -1,5 +1,5 @@
 """The matrix filter's margin is eps (|C|^2 + r^2 + |o|^2), so it works in coordinates about a centre of the scene:
-the spheres' 1/r^2-weighted centroid, the centre of the mesh's vertex box.  A scene moved far from the world origin must (a) still equal
+the median of the spheres' centres, the centre of the mesh's vertex box.  A scene moved far from the world origin must (a) still equal
 the unfiltered kernel pixel for pixel and (b) still be FILTERED — without the centre every pair becomes a candidate there."""
 import numpy as np
 import pytest
