@@ -625,26 +625,34 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
 #ifndef RT3_TILED_TB
 #define RT3_TILED_TB 1024
 #endif
-constexpr uint32_t kTB = RT3_TILED_TB;                              // threads per workgroup of k_trace_mfma_tiled; the fragment tile is kTB * 64 bytes
+#ifndef RT3_TILE_LOADS
+#define RT3_TILE_LOADS 4
+#endif
+#ifndef RT3_BM_BLOCKS
+#define RT3_BM_BLOCKS 16
+#endif
+constexpr uint32_t kTB = RT3_TILED_TB;                              // threads per workgroup of k_trace_mfma_tiled
+constexpr uint32_t kTileLoads = RT3_TILE_LOADS;                     // 16-byte vectors per thread and tile: the fragment tile is kTB * kTileLoads * 16 bytes
+constexpr uint32_t kBmBlocks = RT3_BM_BLOCKS;                       // row blocks scanned before their candidate words are pushed (words: kBmBlocks * kTB * 4 bytes)
 constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;     // k_mode_r_mfma
-constexpr size_t kTraceTiledLdsBytes = (size_t)kTB * (64 + 16 * 4 + 8) + (size_t)(kTB / 64) * kPairCap * 4;
+constexpr size_t kTraceTiledLdsBytes = (size_t)kTB * (kTileLoads * 16 + kBmBlocks * 4 + 8) + (size_t)(kTB / 64) * kPairCap * 4;
 // One tile of fragments through the workgroup: [barrier] loads -> LDS stores [barrier].
-template <uint32_t TB = kMB>
+template <uint32_t TB = kMB, uint32_t LOADS = 4>
 __device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict__ src, uint32_t n_vec, uint32_t tid) {
     __syncthreads();                                                // every wave is done with the previous tile
-    u32x4 v[4];
+    u32x4 v[LOADS];
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) v[i] = src[min(tid + i * TB, n_vec - 1u)];       // unconditional: four loads in flight, no branches
+    for (uint32_t i = 0; i < LOADS; i++) v[i] = src[min(tid + i * TB, n_vec - 1u)];   // unconditional: all loads in flight, no branches
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++) { const uint32_t k = tid + i * TB; if (k < n_vec) s_frag[k] = v[i]; }
+    for (uint32_t i = 0; i < LOADS; i++) { const uint32_t k = tid + i * TB; if (k < n_vec) s_frag[k] = v[i]; }
     __syncthreads();
 }
 template <bool HAS_TRI, bool HAS_SPH, bool REF>
 __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     extern __shared__ u32x4 lds_dyn[];
-    u32x4* s_frag = lds_dyn;                                                   // kTB * 4 vectors: [16][4][64] at 1024 threads
-    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + kTB * 4);            // [16][kTB] candidate words
-    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kTB);   // [kTB] nearest hit of every lane's ray
+    u32x4* s_frag = lds_dyn;                                                   // kTB * kTileLoads vectors: [16][4][64] at 1024 threads x 4
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + kTB * kTileLoads);   // [kBmBlocks][kTB] candidate words
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + kBmBlocks * kTB);   // [kTB] nearest hit of every lane's ray
     uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kTB);              // [waves][kPairCap]
     const uint32_t tid = threadIdx.x, lane = lane_id();
     uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
@@ -683,16 +691,16 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
         auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto&& test) {
             constexpr bool K32 = decltype(k32)::value;                          // spheres: 2 operand fragments (2 KiB) per row block, else 4
             constexpr uint32_t kVec = K32 ? 128u : 256u;
-            constexpr uint32_t kTile = kTB * 4u / kVec;                         // row blocks per tile (64 KiB at 1024 threads): 32 | 16
+            constexpr uint32_t kTile = kTB * kTileLoads / kVec;                 // row blocks per tile (64 KiB at 1024 threads x 4 loads): 32 | 16
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
             for (uint32_t b0 = 0; b0 < total_blocks; b0 += kTile) {
                 const uint32_t nb = min(kTile, total_blocks - b0);
                 RT3_PHASE(pt_rest)
-                fill_tile<kTB>(s_frag, frags + (size_t)b0 * kVec, nb * kVec, tid);
+                fill_tile<kTB, kTileLoads>(s_frag, frags + (size_t)b0 * kVec, nb * kVec, tid);
                 RT3_PHASE(pt_fill)
                 if (live == 0ull) continue;                                     // a wave without rays (the tail of a launch) only keeps the barriers
-                for (uint32_t h0 = 0; h0 < nb; h0 += 16) {                      // the candidate words hold 16 row blocks: scan and push in halves
-                    const uint32_t hb = min(16u, nb - h0);
+                for (uint32_t h0 = 0; h0 < nb; h0 += kBmBlocks) {               // the candidate words hold kBmBlocks row blocks: scan and push in parts
+                    const uint32_t hb = min(kBmBlocks, nb - h0);
                     uint32_t nz;
                     if constexpr (K32) nz = mfma32k_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane);
                     else nz = mfma16_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
