@@ -304,8 +304,28 @@ __device__ __forceinline__ void build_ray_operands16(float ox, float oy, float o
 // The scan of one LDS-resident tile of up to 16 row blocks with the 16x16x32 shape.  Candidate word `blk` of this LANE (see above: four
 // rays x eight rows) goes to bm[blk * STRIDE], bit CLEAR <-> candidate; the return value has bit (n_blocks - 1 - blk) set when that word
 // holds any candidate.  Per row block: 4 ds_read_b128, 16 MFMAs, 32 v_alignbit.
+// Issue priority of this wave (0..3; `p` must be wave-uniform: s_setprio ignores EXEC).
+// The tiled kernels use it to keep the four waves of a SIMD level between two tile barriers.  Instruction issue goes by priority, then
+// age (MI355X_MICROARCH.md), so at equal priority the oldest wave runs ahead, the others take the slots it leaves, they finish a tile one
+// after the other and the youngest ends it alone on its SIMD at the pace of its own dependencies — while in this vector-ALU-bound scan
+// four waves are just enough to fill the issue slots.  With a priority that FALLS with the wave's progress through the tile (four levels:
+// quarters of the tile) a wave that is behind always outranks one that is ahead: they arrive at the barrier together.  Measured in one
+// process (profiles/r02_ab_progress_prio.log): 100 000 spheres x0.938, 47 106 faces x0.969, Mode R x0.964; a rotating priority
+// ((rank + quarter) & 3) instead: x0.961 / x1.019 / x1.009.
+__device__ __forceinline__ void set_prio(uint32_t p) {
+    switch (p) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+#ifndef RT3_PROGRESS_PRIO
+#define RT3_PROGRESS_PRIO 1
+#endif
 template <uint32_t STRIDE = kMB>
-__device__ __forceinline__ uint32_t mfma16_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands16& R, uint32_t* bm, uint32_t lane) {
+__device__ __forceinline__ uint32_t mfma16_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands16& R, uint32_t* bm, uint32_t lane,
+                                                     uint32_t prio_base = 0, uint32_t prio_shift = 2) {
     uint32_t nz = 0;
     if (n_blocks == 0) return nz;
     const u32x4* fr = s_frag + lane;
@@ -315,6 +335,9 @@ __device__ __forceinline__ uint32_t mfma16_scan_tile(const u32x4* s_frag, uint32
     };
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {
         uint32_t* bm0 = bm + b0 * STRIDE;
+#if RT3_PROGRESS_PRIO
+        set_prio(3u - min(3u, (prio_base + b0) >> prio_shift));     // the further into the tile, the lower: laggards catch up
+#endif
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             if (b0 + u >= n_blocks) break;
@@ -414,7 +437,8 @@ __device__ __forceinline__ void build_ray_operands32(float ox, float oy, float o
 }
 // The scan: per row block 2 ds_read_b128, 8 MFMAs, 32 v_alignbit; candidate words exactly as mfma16_scan_tile's.
 template <uint32_t STRIDE = kMB>
-__device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands32& R, uint32_t* bm, uint32_t lane) {
+__device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands32& R, uint32_t* bm, uint32_t lane,
+                                                      uint32_t prio_base = 0, uint32_t prio_shift = 3) {
     uint32_t nz = 0;
     if (n_blocks == 0) return nz;
     const u32x4* fr = s_frag + lane;
@@ -425,6 +449,9 @@ __device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint3
     };
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {
         uint32_t* bm0 = bm + b0 * STRIDE;
+#if RT3_PROGRESS_PRIO
+        set_prio(3u - min(3u, (prio_base + b0) >> prio_shift));     // the further into the tile, the lower: laggards catch up
+#endif
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             if (b0 + u >= n_blocks) break;
@@ -702,7 +729,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                 for (uint32_t h0 = 0; h0 < nb; h0 += kBmBlocks) {               // the candidate words hold kBmBlocks row blocks: scan and push in parts
                     const uint32_t hb = min(kBmBlocks, nb - h0);
                     uint32_t nz;
-                    if constexpr (K32) nz = mfma32k_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane);
+                    if constexpr (K32) nz = mfma32k_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane, h0, 3);
                     else nz = mfma16_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
                     RT3_PHASE(pt_scan)
                     push_pairs16<kTB>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
