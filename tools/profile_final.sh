@@ -6,10 +6,6 @@ export TMPDIR=/tmp
 out=gpurun_out/final
 export RT3_PROFILE_TAG=${RT3_PROFILE_TAG:-r02}
 rm -rf $out && mkdir -p $out
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py > $out/bench_stdout.log 2>$out/bench_stderr.log || exit 1
-echo "trace pass done"
-grep '^{' $out/bench_stdout.log | tail -1 > $out/bench_line.json
-cp $(ls $out/trace/*/*_kernel_stats.csv | head -1) $out/kernel_stats.csv
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
@@ -36,5 +32,12 @@ agg["_command"] = "rocprofv3 --pmc <set> -- python3 bench.py --steps 1 --warmup 
 json.dump(agg, open("gpurun_out/final/pmc_k_trace.json", "w"), indent=1)
 print(json.dumps({k: v["sum_over_dispatches"] for k, v in agg.items() if isinstance(v, dict)}))
 PY
+# the counters first, so that the traced run's JSON line reports them (bench.py reads profiles/${RT3_PROFILE_TAG}_bench_pmc_k_trace.json and
+# checks its source fingerprint)
+cp $out/pmc_k_trace.json profiles/${RT3_PROFILE_TAG}_bench_pmc_k_trace.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py > $out/bench_stdout.log 2>$out/bench_stderr.log || exit 1
+echo "trace pass done"
+grep '^{' $out/bench_stdout.log | tail -1 > $out/bench_line.json
+cp $(ls $out/trace/*/*_kernel_stats.csv | head -1) $out/kernel_stats.csv
 head -5 $out/kernel_stats.csv
 cat $out/bench_line.json | cut -c1-400
