@@ -79,6 +79,9 @@ __host__ __device__ inline void bound_frag_row(float cx, float cy, float cz, flo
 }
 __host__ __device__ inline float filter_kj(double c2, double r2) { return (float)((r2 - c2) + (double)kFilterEps * (c2 + r2)); }
 constexpr float kNeverCandidate = -1e30f, kAlwaysCandidate = 1e30f;
+#ifndef RT3_FACE_K32
+#define RT3_FACE_K32 1                                               // 1: faces go through the K = 32 form like the spheres (fragments: k_commit_mesh);
+#endif                                                              // 0: the K = 64 16x16x32 form (A/B reference; tools/filter_probe measures both)
 
 // Ray-side (B operand) fragments of the 64 rays of a wave: [column set (rays 0..31 / 32..63)][operands 0 and 1, operand 2, operand 3].
 struct RayOperands { u32x4 b[2][3]; };
@@ -378,7 +381,9 @@ __device__ __forceinline__ uint32_t mfma16_scan_tile(const u32x4* s_frag, uint32
 // ONE v_mfma_f32_16x16x32_bf16 per 16 x 16 tile, two ds_read_b128 per row block — with eps = 2.2e-4 covering what is dropped (MM, LH, HL:
 // 3 * 2^-16 per term; bound in DESIGN.md 5.2c) and the coordinates taken about the spheres' centroid, which keeps |C|^2 + |o|^2, and with it
 // the margin, small.  K-slots: A (H x, 1) x (H y, H K) | B (H x, 1) x (M y, M K rounded UP) | D (M x, H E) x (H y, 1) | (M E, L E) x (1, 1).
-// Faces keep the K = 64 form: their exact test costs a 64-byte gather and ~150 instructions, and every extra candidate a push.
+// Faces take the same form: their exact test is dearer (a 64-byte gather, ~150 instructions) and K = 32 doubles their candidates (20 -> 39 per
+// ray cast in the 47 106-face box), but the K = 64 face scan was bound by the matrix pipe itself: x0.82 on that scene, x0.76 on Mode R
+// (profiles/r02_ab_face_k32.log).  -DRT3_FACE_K32=0 keeps the K = 64 form of this shape (mfma16_scan_tile) as the A/B reference.
 constexpr float kFilterEps32 = 2.2e-4f;
 struct RayOperands32 { u32x4 b[4]; };                               // [ray group G]: K-slots 8 g .. 8 g + 7 of ray 16 G + c
 __host__ __device__ inline float filter_kj32(double c2, double r2) { return (float)((r2 - c2) + (double)kFilterEps32 * (c2 + r2)); }
@@ -710,7 +715,11 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
         if (REF && ray.literal) { const float inv = 1.0f / __builtin_sqrtf(dot3(ux, uy, uz, ux, uy, uz)); ux = ux * inv; uy = uy * inv; uz = uz * inv; }
         RayOperands16 R;                                                        // faces: K = 64
         RayOperands32 R32;                                                      // spheres: K = 32, coordinates about the filter centre
+#if RT3_FACE_K32
+        if (HAS_TRI) build_ray_operands32(ray.ox - A.tcx, ray.oy - A.tcy, ray.oz - A.tcz, ux, uy, uz, alive, R32);
+#else
         if (HAS_TRI) build_ray_operands16(ray.ox - A.tcx, ray.oy - A.tcy, ray.oz - A.tcz, ux, uy, uz, alive, R);
+#endif
         if (HAS_SPH && !HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);
         keys[lane] = kKeyNone;
         uint32_t n_pairs = 0;
@@ -754,7 +763,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                 if (!face_inside(n, p1, p2, p3, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t)) return;
                 if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
             };
-            pass(tri_frags, A.n_tri, std::false_type(), test);
+            pass(tri_frags, A.n_tri, std::bool_constant<RT3_FACE_K32 != 0>(), test);
         }
         if (HAS_SPH) {
             if (HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);   // (after the faces' pass: their operands are dead)
@@ -809,8 +818,15 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
     const float dy = ((cam.ly + u * cam.hy) + v * cam.vy) - oy;
     const float dz = ((cam.lz + u * cam.hz) + v * cam.vz) - oz;
     const float inv = 1.0f / __builtin_sqrtf(dot3(dx, dy, dz, dx, dy, dz));     // unit direction for the filter only
+#if RT3_FACE_K32
+    RayOperands32 R;
+    build_ray_operands32(ox - tcx, oy - tcy, oz - tcz, dx * inv, dy * inv, dz * inv, valid_px, R);     // the fragments are about (tcx, tcy, tcz)
+    constexpr uint32_t kVec = 128u, kTile = 32u;
+#else
     RayOperands16 R;
     build_ray_operands16(ox - tcx, oy - tcy, oz - tcz, dx * inv, dy * inv, dz * inv, valid_px, R);     // the fragments are about (tcx, tcy, tcz)
+    constexpr uint32_t kVec = 256u, kTile = 16u;
+#endif
     const LaneRay ray = { ox, oy, oz, dx, dy, dz, true };
     keys[lane] = kKeyNone;
     uint32_t n_pairs = 0;
@@ -828,11 +844,18 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
         if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
     };
     const uint32_t total_blocks = (n_faces + 31u) / 32u;
-    for (uint32_t b0 = 0; b0 < total_blocks; b0 += 16) {
-        const uint32_t nb = min(16u, total_blocks - b0);
-        fill_tile(s_frag, tri_frags + (size_t)b0 * 256, nb * 256, tid);
-        const uint32_t nz = mfma16_scan_tile(s_frag, nb, R, s_bm + tid, lane);
-        push_pairs16(nz, nb, s_bm + tid, b0 * 32u, lane, pairs, n_pairs, test);
+    for (uint32_t b0 = 0; b0 < total_blocks; b0 += kTile) {
+        const uint32_t nb = min(kTile, total_blocks - b0);
+        fill_tile(s_frag, tri_frags + (size_t)b0 * kVec, nb * kVec, tid);
+        for (uint32_t h0 = 0; h0 < nb; h0 += 16) {
+            const uint32_t hb = min(16u, nb - h0);
+#if RT3_FACE_K32
+            const uint32_t nz = mfma32k_scan_tile(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane, h0, 3);
+#else
+            const uint32_t nz = mfma16_scan_tile(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
+#endif
+            push_pairs16(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
+        }
     }
     test_all(lane, pairs, n_pairs, test);
     __builtin_amdgcn_wave_barrier();

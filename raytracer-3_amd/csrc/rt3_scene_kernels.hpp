@@ -101,11 +101,17 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
     // matrix-filter fragments (16x16x32 form): row i of block i/32, both K halves, all four lane groups (padding rows: never candidates)
     auto write_frag = [&](float cx, float cy, float cz, float kj) {
         if (i >= n_frag_rows) return;
+#if RT3_FACE_K32
+        uint32_t fr[4][4];
+        bound_frag32_row(cx, cy, cz, kj, fr);
+        for (uint32_t g = 0; g < 4; g++) frag[frag32_index(i / 32, i % 32, g)] = u32x4{ fr[g][0], fr[g][1], fr[g][2], fr[g][3] };
+#else
         uint32_t fr[2][4][4];
         bound_frag16_row(cx, cy, cz, kj, fr);
         for (uint32_t q = 0; q < 2; q++)
             for (uint32_t g = 0; g < 4; g++)
                 frag[frag16_index(i / 32, i % 32, q, g)] = u32x4{ fr[q][g][0], fr[q][g][1], fr[q][g][2], fr[q][g][3] };
+#endif
     };
     if (i >= n_pad && i >= n_frag_rows) return;
     if (i >= n_faces) { if (all && i < n_pad) bound[i] = kPadSphere; write_frag(0.0f, 0.0f, 0.0f, kNeverCandidate); return; }
@@ -155,7 +161,11 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
         // the filter works in coordinates about the centre of the vertices' box (the VALU scan's `bound` stays in world coordinates)
         const float fx = (float)(cx - (double)centre[0]), fy = (float)(cy - (double)centre[1]), fz = (float)(cz - (double)centre[2]);
         const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
+        #if RT3_FACE_K32
+        write_frag(fx, fy, fz, always ? kAlwaysCandidate : filter_kj32(c2, (double)r2f));
+#else
         write_frag(fx, fy, fz, always ? kAlwaysCandidate : filter_kj(c2, (double)r2f));
+#endif
     }
     if (!all) return;
     if (mats) {
