@@ -78,7 +78,7 @@ def main():
     r.set_mesh(faces, verts, fm)
     cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
     spp5 = 4 if quick else 16
-    run_path(r, "5: cornell 47k tris 1024x1024x%d d50 (of 2048 spp)" % spp5, cam, rt3.make_params(1024, 1024, spp=spp5, max_depth=50, flags=3))
+    run_path(r, "5: cornell 47k tris 1024x1024x%d d50 (of 2048 spp)" % spp5, cam, rt3.make_params(1024, 1024, spp=spp5, max_depth=50, flags=3), k_slots=32)
 
 
 def tiled_only(r):
@@ -94,7 +94,7 @@ def tiled_only(r):
         r.set_spheres(np.zeros((0, 4), np.float32), np.zeros(0, rt3.MATERIAL))
         r.set_mesh(faces, verts, fm)
         cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
-        run_path(r, "5: cornell 47k tris 1024x1024x%d d50" % spp, cam, rt3.make_params(1024, 1024, spp=spp, max_depth=50, flags=3))
+        run_path(r, "5: cornell 47k tris 1024x1024x%d d50" % spp, cam, rt3.make_params(1024, 1024, spp=spp, max_depth=50, flags=3), k_slots=32)
 
 
 if __name__ == "__main__":
