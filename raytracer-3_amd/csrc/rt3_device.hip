@@ -882,6 +882,13 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
     if (ctx->last_was_path) {
         unsigned long long counters[16] = { 0 };
         RT3_HIP(hipMemcpy(counters, ctx->d_casts, 128, hipMemcpyDeviceToHost));
+#ifdef RT3_PROFILE_PHASES
+        if (counters[13] != 0) {                                     // k_trace_mfma: where its waves spend their time
+            const double all = (double)(counters[11] + counters[12] + counters[13] + counters[14] + counters[15]);
+            fprintf(stderr, "[rt3 profile] k_trace_mfma, share of wave time: refill %.1f %%, ray operands %.1f %%, scan %.1f %%, exact tests %.1f %%, shade %.1f %%\n",
+                    100.0 * counters[11] / all, 100.0 * counters[12] / all, 100.0 * counters[13] / all, 100.0 * counters[14] / all, 100.0 * counters[15] / all);
+        }
+#endif
 #ifdef RT3_PROFILE
         if (counters[13] == 0)
         fprintf(stderr, "[rt3 profile] wave iterations %llu, flush iterations/wave-iter %.2f, candidates/ray %.2f, live lanes/wave-iter %.1f, "

@@ -589,8 +589,15 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
     if (lane == 0) { const unsigned long long t0 = wall_clock64(); atomicMin(A.cast_counter + 8, t0); atomicMax(A.cast_counter + 11, t0); }
 #endif
 
+#ifdef RT3_PROFILE_PHASES                                                       // wave time (s_memtime) per part of a trip: tools/README.md
+    unsigned long long ph_refill = 0, ph_operands = 0, ph_scan = 0, ph_flush = 0, ph_shade = 0, ph_mark = clock64();
+#define RT3_SPHASE(acc) { const unsigned long long now_ = clock64(); acc += now_ - ph_mark; ph_mark = now_; }
+#else
+#define RT3_SPHASE(acc)
+#endif
     for (;;) {
         refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
+        RT3_SPHASE(ph_refill)
 #ifdef RT3_PROFILE
         if (exhausted && !prof_dry_seen) {
             prof_dry_seen = true;
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
         const float ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz;
         RayOperands R;
         build_ray_operands(ox - A.fcx, oy - A.fcy, oz - A.fcz, dx, dy, dz, alive, R);      // the fragments are about (fcx, fcy, fcz)
+        RT3_SPHASE(ph_operands)
 
         // nearest hit: exact evaluation of queued candidates (ties: lower sphere index, as the sequential loop)
         float tbest = __builtin_inff();
@@ -624,6 +632,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
             ibest = better ? j : ibest;
         };
         const uint32_t nz = mfma_scan_tile(s_frag, n_blocks, R, s_bm + tid, lane);
+        RT3_SPHASE(ph_scan)
 #ifdef RT3_PROFILE
         {
             uint32_t mine = 0;
@@ -637,9 +646,18 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
         }
 #endif
         mfma_flush(nz, n_blocks, s_bm + tid, eval);
+        RT3_SPHASE(ph_flush)
         kind = tbest < __builtin_inff() ? 2u : 0u;
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
+        RT3_SPHASE(ph_shade)
     }
+#ifdef RT3_PROFILE_PHASES
+    if (lane == 0) {
+        atomicAdd(A.cast_counter + 11, ph_refill); atomicAdd(A.cast_counter + 12, ph_operands); atomicAdd(A.cast_counter + 13, ph_scan);
+        atomicAdd(A.cast_counter + 14, ph_flush); atomicAdd(A.cast_counter + 15, ph_shade);
+    }
+#endif
+#undef RT3_SPHASE
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); }
 #ifdef RT3_PROFILE
     if (lane == 0) {
