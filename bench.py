@@ -310,15 +310,22 @@ def main():
         full_workload = world == 1 and (W, H, args.spp, args.depth) == (WIDTH, HEIGHT, SPP, DEPTH)
         traffic, traffic_source, valu = counters_from_profile(fingerprint) if full_workload else (None, "not the profiled workload", None)
         if st.mfma_instructions:
-            roofline = {"bound": "mfma", "kernel": "k_trace_mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(mfma_tf / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            k32 = st.mfma_flop_per_instruction == 16384                      # k_trace_mfma32 (default) | k_trace_mfma (RT3_MFMA_K64=1, round 1's form)
+            roofline = {"bound": "mfma", "kernel": "k_trace_mfma32" if k32 else "k_trace_mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(mfma_tf / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                         "kernel_ms": round(k_ms, 3), "launches_per_step": launches, "mfma_instructions_per_launch": int(st.mfma_instructions / n_launch),
+                        "mfma_instruction": "v_mfma_f32_16x16x32_bf16" if k32 else "v_mfma_f32_32x32x16_bf16",
+                        "flop_per_mfma_instruction": int(st.mfma_flop_per_instruction), "filter_k": 32 if k32 else 64,
+                        # the same test rate priced in round 1's K = 64 form (128 FLOP per test): for comparisons across rounds, not executed work
+                        "k64_equivalent_frac": round(st.prim_tests * 128.0 / n_launch / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if k_ms > 0 else 0.0,
                         "live": ["achieved", "frac", "kernel_ms", "mfma_instructions_per_launch (counted by the kernel)"],
                         "valu_issue": valu, "kernel_sources": fingerprint,
-                        "note": "EXECUTED work of the dominant kernel: v_mfma_f32_32x32x16_bf16 wave-instructions x 32768 FLOP / kernel time (HIP "
-                                "events on the launch stream) over the dense bf16 peak.  The kernel evaluates the discriminant of every (ray, sphere) "
-                                "pair as a bf16x3-split contraction on the matrix cores (DESIGN.md 5.2b); beside the matrix pipe it keeps the vector "
-                                "ALU issuing (valu_issue).  The sustained clock under this load is ~2.0-2.1 GHz of the 2.4 GHz the peak assumes"}
+                        "note": "EXECUTED work of the dominant kernel: matrix wave-instructions x FLOP per instruction / kernel time (HIP events on the "
+                                "launch stream) over the dense bf16 peak.  The kernel evaluates the discriminant of every (ray, sphere) pair as a "
+                                "split-bf16 contraction on the matrix cores (DESIGN.md 5.2b) and is bound by vector-ALU instruction issue beside it "
+                                "(valu_issue: one v_alignbit per pair decodes the sign bits).  Round 2's K = 32 form executes HALF the matrix work per "
+                                "test of round 1's K = 64 form, so this fraction fell (0.50 -> 0.32) while the kernel got 20 % faster: the chip "
+                                "throttles less (2.0-2.2 GHz -> ~2.3 GHz) and an issue-bound kernel runs at the clock"}
         else:
             roofline = {"bound": "mfma", "kernel": "k_trace (vector-ALU scan, RT3_NO_MFMA / RT3_BRUTE)", "achieved": 0.0, "peak": PEAK_BF16_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": 0.0, "traffic": None, "traffic_source": "A/B build, not profiled", "kernel_ms": round(k_ms, 3),

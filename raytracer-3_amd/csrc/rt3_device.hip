@@ -57,7 +57,7 @@ struct rt3_ctx {
     rt3_material* d_face_mats_in = nullptr; uint32_t* d_error = nullptr;
     // spheres
     uint32_t n_sph = 0;
-    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; float tri_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t* d_box = nullptr; uint32_t* d_tri_frag_r = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
+    float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t n_direct = 0; uint32_t direct[4] = { 0, 0, 0, 0 }; float tri_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t* d_box = nullptr; uint32_t* d_tri_frag_r = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
     // work buffers
     Rgb* d_rad = nullptr; size_t rad_entries = 0;
@@ -192,12 +192,17 @@ float4 pack_material(const rt3_material& m) {
 // Lane l holds, for operand row (l & 31) — sphere b of the block sits in row frag_row_of(b) — K elements 8 (l >> 5) .. +7;
 // padding rows can never be candidates.  Coordinates relative to `centre` (sphere_filter_centre: it keeps |C|^2 + |o|^2, and with it the
 // filter's margin, small for a scene that is not built around the world origin).
-std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n, const float centre[3]) {
+// Rows of `direct` spheres (sphere_direct_list below) can never be candidates: the kernels test those spheres for every ray anyway.
+bool is_direct(uint32_t j, const uint32_t* direct, uint32_t n_direct) {
+    for (uint32_t i = 0; i < n_direct; i++) if (direct[i] == j) return true;
+    return false;
+}
+std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n, const float centre[3], const uint32_t* direct, uint32_t n_direct) {
     const uint32_t blocks = (n + 31u) / 32u;
     std::vector<uint32_t> out((size_t)blocks * 4 * 64 * 4, 0u);
     for (uint32_t j = 0; j < blocks * 32; j++) {
         uint32_t fr[4][2][4];
-        if (j < n) {
+        if (j < n && !is_direct(j, direct, n_direct)) {
             const float* s = center_radius + 4 * (size_t)j;
             const float cx = (float)((double)s[0] - centre[0]), cy = (float)((double)s[1] - centre[1]), cz = (float)((double)s[2] - centre[2]);
             const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz, r2 = (double)s[3] * s[3];
@@ -212,12 +217,12 @@ std::vector<uint32_t> build_sphere_frags(const float* center_radius, uint32_t n,
 
 // The same spheres as fragments of the K = 32 form of the tiled kernels (rt3_matrix_filter.hpp): [row block][h][lane 16 g + c] x 8 bf16,
 // coordinates relative to the same centre.
-std::vector<uint32_t> build_sphere_frags32(const float* center_radius, uint32_t n, const float centre[3]) {
+std::vector<uint32_t> build_sphere_frags32(const float* center_radius, uint32_t n, const float centre[3], const uint32_t* direct, uint32_t n_direct) {
     const uint32_t blocks = (n + 31u) / 32u;
     std::vector<uint32_t> out((size_t)blocks * 2 * 64 * 4, 0u);
     for (uint32_t j = 0; j < blocks * 32; j++) {
         uint32_t fr[4][4];
-        if (j < n) {
+        if (j < n && !is_direct(j, direct, n_direct)) {
             const float* s = center_radius + 4 * (size_t)j;
             const float cx = (float)((double)s[0] - centre[0]), cy = (float)((double)s[1] - centre[1]), cz = (float)((double)s[2] - centre[2]);
             const double c2 = (double)cx * cx + (double)cy * cy + (double)cz * cz, r2 = (double)s[3] * s[3];
@@ -243,6 +248,31 @@ void sphere_filter_centre(const float* center_radius, uint32_t n, float out[3]) 
         std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
         out[a] = v[v.size() / 2];
     }
+}
+
+// Spheres that (nearly) every ray is a candidate for: the line of a ray that starts in the middle of the scene meets a sphere whose radius
+// is comparable to its distance from there — the book scene's ground (r = 1000, its centre 1000 away), a sphere around the scene's middle.
+// The filter cannot reject them and each costs the pair list one entry per ray, so the matrix-filter kernels test them directly instead
+// (TraceArgs::direct).  Any choice is correct; this one takes the (at most four) spheres with the largest r / |centre - c0| above 1/2.
+uint32_t sphere_direct_list(const float* center_radius, uint32_t n, const float c0[3], uint32_t out[4]) {
+    float best[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const float* s = center_radius + 4 * (size_t)i;
+        const double dx = (double)s[0] - c0[0], dy = (double)s[1] - c0[1], dz = (double)s[2] - c0[2];
+        const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+        const float ratio = (float)((double)s[3] / std::max(dist, 1e-30));
+        if (!(ratio >= 0.5f)) continue;                             // (NaN: not chosen)
+        uint32_t k = count < 4 ? count++ : 4;
+        if (k == 4) {                                               // replace the weakest if this one is stronger
+            uint32_t w = 0;
+            for (uint32_t q = 1; q < 4; q++) if (best[q] < best[w]) w = q;
+            if (!(ratio > best[w])) continue;
+            k = w;
+        }
+        best[k] = ratio; out[k] = i;
+    }
+    return count;
 }
 
 bool row_owned(const rt3_params* p, uint32_t y) {
@@ -478,8 +508,9 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
     }
     int rc;
     sphere_filter_centre(center_radius, n, ctx->sph_centre);
-    if ((rc = upload(ctx, &ctx->d_sph_frag, build_sphere_frags(center_radius, n, ctx->sph_centre)))) return rc;        // k_trace_mfma (32x32x16 form)
-    if ((rc = upload(ctx, &ctx->d_sph_frag32, build_sphere_frags32(center_radius, n, ctx->sph_centre)))) return rc;    // tiled kernels (K = 32 form)
+    ctx->n_direct = sphere_direct_list(center_radius, n, ctx->sph_centre, ctx->direct);
+    if ((rc = upload(ctx, &ctx->d_sph_frag, build_sphere_frags(center_radius, n, ctx->sph_centre, ctx->direct, ctx->n_direct)))) return rc;      // k_trace_mfma (K = 64, 32x32x16)
+    if ((rc = upload(ctx, &ctx->d_sph_frag32, build_sphere_frags32(center_radius, n, ctx->sph_centre, ctx->direct, ctx->n_direct)))) return rc;  // K = 32 form
     if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
         (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
         return rc;
@@ -667,6 +698,8 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     A.rad = ctx->d_rad; A.work_counter = ctx->d_work; A.cast_counter = ctx->d_casts;
     A.fcx = ctx->sph_centre[0]; A.fcy = ctx->sph_centre[1]; A.fcz = ctx->sph_centre[2];
     A.tcx = ctx->tri_centre[0]; A.tcy = ctx->tri_centre[1]; A.tcz = ctx->tri_centre[2];
+    A.n_direct = ctx->n_direct;
+    for (int i = 0; i < 4; i++) A.direct[i] = ctx->direct[i];
 
     // ---- which kernel
     //   brute         every ray against every primitive (debug switch / RT3_BRUTE=1; REFERENCE_PRIMARY with a camera off the origin or a lens)
@@ -680,6 +713,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     const bool brute = ctx->force_brute || getenv("RT3_BRUTE") || (ref && !(cam_at_origin && !(p->lens_radius > 0.0f)));
     const bool use_mfma = !brute && !getenv("RT3_NO_MFMA");
     const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && !getenv("RT3_FORCE_TILED");   // (A/B knob)
+    const bool single_k64 = mfma_single && getenv("RT3_MFMA_K64") != nullptr;
     const bool sph_lds = has_sph && ctx->n_sph <= kSphLdsMax;
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
     TraceKernel plain = nullptr;
@@ -691,9 +725,11 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         plain = ref ? k_trace_brute<true> : k_trace_brute<false>;
         kptr = (const void*)plain;
     } else if (mfma_single) {
-        lds = (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)kBitmapBytes;
+        // k_trace_mfma32 (K = 32 form, pair list); RT3_MFMA_K64=1: k_trace_mfma, round 1's K = 64 form on v_mfma_f32_32x32x16_bf16 (A/B reference)
+        lds = single_k64 ? (size_t)mfma_blocks * (4096 + 32 * (16 + 16 + 4 + 4)) + (size_t)kBitmapBytes
+                         : (size_t)mfma_blocks * (2048 + 32 * (16 + 16 + 4 + 4)) + (size_t)kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;
         block = kMB;
-        kptr = (const void*)k_trace_mfma;
+        kptr = single_k64 ? (const void*)k_trace_mfma : (const void*)k_trace_mfma32;
     } else if (use_mfma) {
         tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
                         : k_trace_mfma_tiled<false, true, false>;
@@ -729,7 +765,8 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         if ((rc = take_event_pair(ctx, &a, &b))) return rc;
         RT3_HIP(hipMemsetAsync(ctx->d_work, 0, 4, stream));
         RT3_HIP(hipEventRecord(a, stream));
-        if (mfma_single) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
+        if (mfma_single && single_k64) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
+        else if (mfma_single) hipLaunchKernelGGL(k_trace_mfma32, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag32, mfma_blocks);
         else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kTB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag32);
         else hipLaunchKernelGGL(plain, dim3(grid), dim3(kBlock), lds, stream, A);
         RT3_HIP(hipGetLastError());
@@ -746,7 +783,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     ctx->last_stream = stream;
     ctx->last_samples = (uint64_t)npix * sample_count;
     ctx->last_was_path = true;
-    ctx->last_mfma16 = tiled != nullptr;
+    ctx->last_mfma16 = tiled != nullptr || (mfma_single && !single_k64);
     ctx->rendered = true;
     ctx->acc_valid = true; ctx->acc_params = *p; ctx->acc_cam = *cam; ctx->acc_done = sample_begin + sample_count; ctx->acc_npix = npix;
     return 0;

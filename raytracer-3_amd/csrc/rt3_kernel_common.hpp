@@ -125,7 +125,11 @@ struct TraceArgs {
     // Centres the matrix filter's coordinates are taken about: the filter's margin is eps (|C|^2 + r^2 + |o|^2), so a scene far from the
     // world origin would otherwise drown in candidates.  Spheres: the median of their centres; faces: the centre of the vertices' box.
     float fcx, fcy, fcz;     // spheres (k_trace_mfma, the K = 32 pass of k_trace_mfma_tiled)
-    float tcx, tcy, tcz;     // faces (the K = 64 pass of k_trace_mfma_tiled)
+    float tcx, tcy, tcz;     // faces (the faces' pass of k_trace_mfma_tiled)
+    // Spheres that nearly every ray is a candidate for (a ground sphere; a sphere around the middle of the scene) gain nothing from the
+    // filter and cost the pair list 64 entries per ray cast each: they are tested directly, every lane its own ray, and their fragment
+    // rows can never be candidates (sphere_direct_list in rt3_device.hip).  Matrix-filter kernels only.
+    uint32_t n_direct; uint32_t direct[4];
     uint32_t* work_counter;
     unsigned long long* cast_counter;
 };

@@ -441,7 +441,7 @@ __device__ __forceinline__ void build_ray_operands32(float ox, float oy, float o
     }
 }
 // The scan: per row block 2 ds_read_b128, 8 MFMAs, 32 v_alignbit; candidate words exactly as mfma16_scan_tile's.
-template <uint32_t STRIDE = kMB>
+template <uint32_t STRIDE = kMB, bool PRIO = true>                  // PRIO: progress priority (kernels whose waves meet at tile barriers)
 __device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands32& R, uint32_t* bm, uint32_t lane,
                                                       uint32_t prio_base = 0, uint32_t prio_shift = 3) {
     uint32_t nz = 0;
@@ -455,7 +455,7 @@ __device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint3
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {
         uint32_t* bm0 = bm + b0 * STRIDE;
 #if RT3_PROGRESS_PRIO
-        set_prio(3u - min(3u, (prio_base + b0) >> prio_shift));     // the further into the tile, the lower: laggards catch up
+        if constexpr (PRIO) set_prio(3u - min(3u, (prio_base + b0) >> prio_shift));     // the further into the tile, the lower: laggards catch up
 #endif
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
@@ -501,6 +501,20 @@ __device__ __forceinline__ void key_decode(unsigned long long key, uint32_t& kin
     kind = key == kKeyNone ? 0u : 1u + (lo >> 31);
     idx = (lo & 0x7FFFFFFFu) >> 1;
     t = __uint_as_float(hi | (lo << 31));
+}
+// The direct spheres (TraceArgs::direct): every lane tests its own ray; returns the key the ray's record starts from.
+template <class SphereAt>
+__device__ __forceinline__ unsigned long long direct_tests(const TraceArgs& A, float ox, float oy, float oz, float dx, float dy, float dz, SphereAt&& sphere_at) {
+    unsigned long long key = kKeyNone;
+    for (uint32_t i = 0; i < A.n_direct; i++) {
+        const uint32_t j = A.direct[i];
+        float t;
+        if (sphere_root(sphere_at(j), ox, oy, oz, dx, dy, dz, A.t_min, t) && t < __builtin_inff()) {
+            const unsigned long long k = hit_key(t, 1u, j);
+            key = k < key ? k : key;
+        }
+    }
+    return key;
 }
 // Rays of the wave as the exact tests fetch them from the owning lane.
 struct LaneRay { float ox, oy, oz, dx, dy, dz; bool literal; };
@@ -646,6 +660,13 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
         }
 #endif
         mfma_flush(nz, n_blocks, s_bm + tid, eval);
+        {                                                                       // the direct spheres (not in the filter): (t, index) order as the pair-list kernels' key
+            uint32_t dk, di; float dt;
+            key_decode(direct_tests(A, ox, oy, oz, dx, dy, dz, [&](uint32_t j) { return s_sph[j]; }), dk, di, dt);
+            const bool better = dk != 0u && (dt < tbest || (dt == tbest && di < ibest));
+            tbest = better ? dt : tbest;
+            ibest = better ? di : ibest;
+        }
         RT3_SPHASE(ph_flush)
         kind = tbest < __builtin_inff() ? 2u : 0u;
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
@@ -666,6 +687,75 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32
         atomicMin(A.cast_counter + 6, now); atomicMax(A.cast_counter + 7, now);
     }
 #endif
+}
+
+// The same scene class (<= 512 spheres, everything in LDS, no barrier after the prologue) on the K = 32 form: ONE v_mfma_f32_16x16x32_bf16
+// per 16 x 16 tests, 64 B of fragments per sphere, candidates through the pair list, exact tests on the LDS mirror of the spheres.
+// The vector-ALU instruction count per ray cast is that of k_trace_mfma (the K = 32 margin brings more candidates, the pair list tests them
+// at full lane utilisation, the ray operands cost half), but the matrix pipe does half the work and the chip, which throttles under
+// k_trace_mfma's load (2.0-2.2 GHz), holds 2.3-2.4 GHz here — and a kernel bound by vector-ALU issue runs at the clock.
+__global__ __launch_bounds__(kMB) void k_trace_mfma32(const TraceArgs A, const u32x4* __restrict__ frags, uint32_t n_blocks) {
+    extern __shared__ u32x4 lds_dyn[];
+    u32x4* s_frag = lds_dyn;                                                   // [n_blocks][2][64]
+    float4* s_sph = reinterpret_cast<float4*>(s_frag + (size_t)n_blocks * 128);   // [n_blocks * 32] (cx, cy, cz, r^2) for the exact test
+    float4* s_mat = s_sph + (size_t)n_blocks * 32;                               // materials, kinds, 1/r: read at every hit
+    float* s_invr = reinterpret_cast<float*>(s_mat + (size_t)n_blocks * 32);
+    uint32_t* s_kind = reinterpret_cast<uint32_t*>(s_invr + (size_t)n_blocks * 32);
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_kind + (size_t)n_blocks * 32); // [16][kMB] candidate words
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + 16 * kMB);   // [kMB] nearest hit of every lane's ray
+    uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kMB);              // [16 waves][kPairCap]
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
+    unsigned long long* keys = s_key + (tid & ~63u);
+    for (uint32_t k = tid; k < n_blocks * 128; k += kMB) s_frag[k] = frags[k];
+    for (uint32_t k = tid; k < n_blocks * 32; k += kMB) {
+        const bool in = k < A.n_sph;
+        s_sph[k] = in ? A.sph[k] : kPadSphere;
+        s_mat[k] = in ? A.sph_mat[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_invr[k] = in ? A.sph_invr[k] : 0.0f;
+        s_kind[k] = in ? A.sph_kind[k] : 0u;
+    }
+    __syncthreads();                                                            // the only barrier
+
+    Path P;
+    P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
+    P.tr = P.tg = P.tb = 0.0f; P.lr = P.lg = P.lb = 0.0f; P.slot = 0; P.base = 0; P.depth = 0;
+    bool alive = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+    RayStock Q;
+    Q.ox = Q.oy = Q.oz = 0.0f; Q.dx = Q.dy = 0.0f; Q.dz = 1.0f; Q.slot = 0; Q.base = 0; Q.n = 0;
+    unsigned long long casts = 0, iters = 0, exact = 0;
+
+    for (;;) {
+        refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
+        const unsigned long long live = __ballot(alive);
+        if (live == 0ull) break;
+        casts += (unsigned long long)__popcll(live);
+        iters++;
+        const LaneRay ray = { P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, false };
+        RayOperands32 R;
+        build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ray.dx, ray.dy, ray.dz, alive, R);
+        keys[lane] = direct_tests(A, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, [&](uint32_t j) { return s_sph[j]; });
+        uint32_t n_pairs = 0;
+        auto test = [&](uint32_t pair, bool valid) {
+            const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
+            const LaneRay r = fetch_ray<false>(ray, src);
+            exact += (unsigned long long)__popcll(__ballot(valid));
+            if (!valid) return;                                                 // (padding rows are never candidates; s_sph covers every row)
+            float t;
+            if (sphere_root(s_sph[j], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 1u, j));
+        };
+        const uint32_t nz = mfma32k_scan_tile<kMB, false>(s_frag, n_blocks, R, s_bm + tid, lane);
+        push_pairs16<kMB>(nz, n_blocks, s_bm + tid, 0u, lane, pairs, n_pairs, test);
+        test_all(lane, pairs, n_pairs, test);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t kind, ibest;
+        float tbest;
+        key_decode(keys[lane], kind, ibest, tbest);
+        shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
+    }
+    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); atomicAdd(A.cast_counter + 2, exact); }
 }
 
 // Any scene: faces (through their bounding spheres) and spheres, streamed through LDS in tiles of 512 rows.  The 16 waves of the
@@ -739,7 +829,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
         if (HAS_TRI) build_ray_operands16(ray.ox - A.tcx, ray.oy - A.tcy, ray.oz - A.tcz, ux, uy, uz, alive, R);
 #endif
         if (HAS_SPH && !HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);
-        keys[lane] = kKeyNone;
+        keys[lane] = HAS_SPH ? direct_tests(A, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, [&](uint32_t j) { return A.sph[j]; }) : kKeyNone;
         uint32_t n_pairs = 0;
 
         auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto&& test) {

@@ -96,3 +96,17 @@ def test_filters_agree_with_brute_and_the_oracle_on_random_soups(rt3, renderer, 
         assert np.array_equal(hip_render(renderer, case, upload=False), brute)
     finally:
         del os.environ["RT3_NO_MFMA"]
+
+
+def test_the_k64_form_of_the_small_scene_kernel_equals_the_default(renderer):
+    """k_trace_mfma (round 1's K = 64 filter on v_mfma_f32_32x32x16_bf16, RT3_MFMA_K64=1) is kept as the A/B reference of k_trace_mfma32."""
+    case = mode_x_cases()["three_spheres_64x36x16_d8"]
+    want = hip_render(renderer, case)
+    st = renderer.stats()
+    assert st.mfma_flop_per_instruction == 16384             # (all three spheres of this case are on the direct list: no filter candidates)
+    os.environ["RT3_MFMA_K64"] = "1"
+    try:
+        assert np.array_equal(hip_render(renderer, case, upload=False), want)
+        assert renderer.stats().mfma_flop_per_instruction == 32768
+    finally:
+        del os.environ["RT3_MFMA_K64"]

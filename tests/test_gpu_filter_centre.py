@@ -40,7 +40,7 @@ def test_faces_far_from_the_origin_stay_filtered(rt3, renderer):
     assert 0 < per_cast[0] < 60 and per_cast[1] < 6 * per_cast[0] + 20, per_cast
 
 
-@pytest.mark.parametrize("n", [300, 2000])                  # k_trace_mfma (all in LDS) | the K = 32 pass of the tiled kernel
+@pytest.mark.parametrize("n", [300, 2000])                  # k_trace_mfma32 (all in LDS) | the sphere pass of the tiled kernel
 def test_spheres_far_from_the_origin_stay_filtered(rt3, renderer, n):
     rng = np.random.default_rng(n)
     base = np.zeros((n, 4), np.float32)
@@ -58,5 +58,4 @@ def test_spheres_far_from_the_origin_stay_filtered(rt3, renderer, n):
         cam = rt3.Camera().look_at(64, 48, (dx, dy + 1.0, dz + 2.0), (dx, dy, dz - 8.0), (0.0, 1.0, 0.0), 50.0, 1.0)
         case = dict(cam=cam.c, spheres=cr, smats=mats, params=dict(width=64, height=48, spp=4, max_depth=8, seed=5, flags=1, t_min=0.001))
         per_cast.append(render_both(renderer, case))
-    if n > 512:                                             # (k_trace_mfma does not count its exact tests)
-        assert 0 < per_cast[0] < 40 and per_cast[1] < 3 * per_cast[0] + 5, per_cast
+    assert 0 < per_cast[0] < 40 and per_cast[1] < 3 * per_cast[0] + 5, per_cast
