@@ -11,9 +11,11 @@ puts them at their frame rows with one indexed copy.  Total work is fixed, so sc
 N = 1: the rows go through rt3_gather_rows (the C ABI's device-to-device gather), no collective.
 
 Prints one JSON line (rank 0).  Beside the driver's fields:
-  roofline         the dominant kernel (k_trace_mfma) against the bound it actually runs on: EXECUTED bf16 matrix FLOP
-                   (v_mfma_f32_32x32x16_bf16 instructions counted by the kernel itself x 32768) / kernel time measured
-                   live with HIP events on the launch stream, over the 2.5 PFLOP/s dense bf16 peak.  `live` names the
+  roofline         the dominant kernel (k_trace_mfma32) against the matrix roofline: EXECUTED bf16 matrix FLOP
+                   (v_mfma_f32_16x16x32_bf16 instructions counted by the kernel itself x 16384) / kernel time measured
+                   live with HIP events on the launch stream, over the 2.5 PFLOP/s dense bf16 peak; `valu_issue` is the
+                   unit the kernel is actually bound by, `k64_equivalent_frac` the same test rate priced in round 1's
+                   K = 64 form (that kernel, RT3_MFMA_K64=1, executes twice the matrix work per test).  `live` names the
                    fields measured in this run; `traffic` and `valu_issue` are hardware-counter figures that only
                    rocprofv3 can collect — they are taken from the committed profile of this same command and carry
                    its provenance, or are null when that profile was made from other kernel sources
@@ -133,10 +135,15 @@ def counters_from_profile(fingerprint):
     try:
         traffic = int((2.0 * pmc["FETCH_SIZE"]["sum_over_dispatches"] / pmc["FETCH_SIZE"]["dispatches"] +
                        pmc["WRITE_SIZE"]["sum_over_dispatches"] / pmc["WRITE_SIZE"]["dispatches"]) * 1024)
-        busy = pmc["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0 / (pmc["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0)
-        valu = {"frac": round(busy, 3), "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] / pmc["SQ_INSTS_VALU"]["dispatches"]),
-                "source": src, "note": "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x busy cycles): vector-ALU instruction issue, the resource "
-                                       "this kernel saturates beside the matrix pipe"}
+        cycles = pmc["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0                     # SIMD-cycles over all dispatches
+        n_valu = pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] - pmc["SQ_INSTS_MFMA"]["sum_over_dispatches"]
+        valu = {"frac": round(n_valu * 4.0 / cycles, 3),
+                "active_inst_valu_ratio": round(pmc["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0 / cycles, 3),
+                "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] / pmc["SQ_INSTS_VALU"]["dispatches"]),
+                "source": src, "note": "frac = (SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 cycles / (1024 SIMDs x busy cycles): issue slots of the vector ALU "
+                                       "taken by its own (non-matrix) instructions, the resource this kernel saturates; active_inst_valu_ratio = "
+                                       "SQ_ACTIVE_INST_VALU x 4 / the same cycles counts the matrix instructions too, which issue beside the vector "
+                                       "ALU's, and can therefore exceed 1"}
         return traffic, src, valu
     except (KeyError, ZeroDivisionError):
         return None, "%s lacks FETCH_SIZE / WRITE_SIZE" % PMC_PROFILE, None
@@ -203,7 +210,7 @@ def extra_workloads(rt3, r, np):
                     "note": "reference_cpu_s: the reference's SequentialRenderer on this frame, 1 thread, measured by the survey (SURVEY.md §6); "
                             "pixels equal the reference's PPM SHA-256 (tests/test_gpu_mode_r.py)"})
         r.set_mesh(empty_f, empty_v)
-    # (config 3 runs the headline kernel on the headline scene: leaving it out keeps k_trace_mfma's rocprofv3 average = the headline launch)
+    # (config 3 runs the headline kernel on the headline scene: leaving it out keeps k_trace_mfma32's rocprofv3 average = the headline launch)
     # config 4: 100 000 spheres
     cr, mats = rt3.scene_stress(100000, 43)
     r.set_mesh(empty_f, empty_v)
