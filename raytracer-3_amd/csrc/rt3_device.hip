@@ -250,18 +250,30 @@ void sphere_filter_centre(const float* center_radius, uint32_t n, float out[3]) 
     }
 }
 
-// Spheres that (nearly) every ray is a candidate for: the line of a ray that starts in the middle of the scene meets a sphere whose radius
-// is comparable to its distance from there — the book scene's ground (r = 1000, its centre 1000 away), a sphere around the scene's middle.
-// The filter cannot reject them and each costs the pair list one entry per ray, so the matrix-filter kernels test them directly instead
-// (TraceArgs::direct).  Any choice is correct; this one takes the (at most four) spheres with the largest r / |centre - c0| above 1/2.
+// Spheres that (nearly) every ray is a candidate for: the line of a ray that starts somewhere in the scene meets a sphere whose radius is
+// comparable to its distance from there — the book scene's ground (r = 1000, its centre 1000 away).  The filter cannot reject such a sphere
+// and it costs the pair list one entry per ray, so the matrix-filter kernels test it directly instead (TraceArgs::direct).  Any choice is
+// correct; this one takes the (at most four) spheres with the largest r / max(|centre - c0|, R) above 1/2, R = the median distance of the
+// centres from c0, i.e. the scene's own size: a unit sphere in the middle of the book scene (candidate for a few per cent of the rays) stays
+// in the filter — a direct test costs every ray ~30 instructions.
 uint32_t sphere_direct_list(const float* center_radius, uint32_t n, const float c0[3], uint32_t out[4]) {
-    float best[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-    uint32_t count = 0;
+    std::vector<double> dist(n);
     for (uint32_t i = 0; i < n; i++) {
         const float* s = center_radius + 4 * (size_t)i;
         const double dx = (double)s[0] - c0[0], dy = (double)s[1] - c0[1], dz = (double)s[2] - c0[2];
-        const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
-        const float ratio = (float)((double)s[3] / std::max(dist, 1e-30));
+        dist[i] = std::sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    double scene = 0.0;
+    if (n) {
+        std::vector<double> d(dist);
+        for (double& v : d) if (!std::isfinite(v)) v = 0.0;
+        std::nth_element(d.begin(), d.begin() + d.size() / 2, d.end());
+        scene = d[d.size() / 2];
+    }
+    float best[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const float ratio = (float)((double)center_radius[4 * (size_t)i + 3] / std::max(std::max(dist[i], scene), 1e-30));
         if (!(ratio >= 0.5f)) continue;                             // (NaN: not chosen)
         uint32_t k = count < 4 ? count++ : 4;
         if (k == 4) {                                               // replace the weakest if this one is stronger
@@ -922,7 +934,8 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
 #ifdef RT3_PROFILE_PHASES
         if (counters[13] != 0) {                                     // k_trace_mfma: where its waves spend their time
             const double all = (double)(counters[11] + counters[12] + counters[13] + counters[14] + counters[15]);
-            fprintf(stderr, "[rt3 profile] k_trace_mfma, share of wave time: refill %.1f %%, ray operands %.1f %%, scan %.1f %%, exact tests %.1f %%, shade %.1f %%\n",
+            fprintf(stderr, "[rt3 profile] k_trace_mfma32 / k_trace_mfma, share of wave time: refill %.1f %%, ray operands (+ direct spheres) %.1f %%, scan %.1f %%, "
+                            "push + exact tests %.1f %%, decode + shade %.1f %%\n",
                     100.0 * counters[11] / all, 100.0 * counters[12] / all, 100.0 * counters[13] / all, 100.0 * counters[14] / all, 100.0 * counters[15] / all);
         }
 #endif

@@ -726,9 +726,16 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma32(const TraceArgs A, const u
     RayStock Q;
     Q.ox = Q.oy = Q.oz = 0.0f; Q.dx = Q.dy = 0.0f; Q.dz = 1.0f; Q.slot = 0; Q.base = 0; Q.n = 0;
     unsigned long long casts = 0, iters = 0, exact = 0;
+#ifdef RT3_PROFILE_PHASES                                                       // wave time (s_memtime) per part of a trip: tools/README.md
+    unsigned long long ph_refill = 0, ph_operands = 0, ph_scan = 0, ph_flush = 0, ph_shade = 0, ph_mark = clock64();
+#define RT3_SPHASE(acc) { const unsigned long long now_ = clock64(); acc += now_ - ph_mark; ph_mark = now_; }
+#else
+#define RT3_SPHASE(acc)
+#endif
 
     for (;;) {
         refill_from_stock(A, lane, alive, P, Q, chunk_next, chunk_end, exhausted);
+        RT3_SPHASE(ph_refill)
         const unsigned long long live = __ballot(alive);
         if (live == 0ull) break;
         casts += (unsigned long long)__popcll(live);
@@ -746,15 +753,26 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma32(const TraceArgs A, const u
             float t;
             if (sphere_root(s_sph[j], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 1u, j));
         };
+        RT3_SPHASE(ph_operands)
         const uint32_t nz = mfma32k_scan_tile<kMB, false>(s_frag, n_blocks, R, s_bm + tid, lane);
+        RT3_SPHASE(ph_scan)
         push_pairs16<kMB>(nz, n_blocks, s_bm + tid, 0u, lane, pairs, n_pairs, test);
         test_all(lane, pairs, n_pairs, test);
+        RT3_SPHASE(ph_flush)
         __builtin_amdgcn_wave_barrier();
         uint32_t kind, ibest;
         float tbest;
         key_decode(keys[lane], kind, ibest, tbest);
         shade_lane<false, true>(A, P, alive, kind, ibest, tbest, s_sph, s_invr, s_mat, s_kind);
+        RT3_SPHASE(ph_shade)
     }
+#ifdef RT3_PROFILE_PHASES
+    if (lane == 0) {
+        atomicAdd(A.cast_counter + 11, ph_refill); atomicAdd(A.cast_counter + 12, ph_operands); atomicAdd(A.cast_counter + 13, ph_scan);
+        atomicAdd(A.cast_counter + 14, ph_flush); atomicAdd(A.cast_counter + 15, ph_shade);
+    }
+#endif
+#undef RT3_SPHASE
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); atomicAdd(A.cast_counter + 2, exact); }
 }
 
