@@ -1,4 +1,7 @@
-// rt3_matrix_filter.hpp — the candidate filter on the matrix cores and its kernels: k_trace_mfma, k_trace_mfma_tiled, k_mode_r_mfma
+// rt3_matrix_filter.hpp — the candidate filter on the matrix cores and its kernels: k_trace_mfma32 (scenes of <= 512 spheres: the bench
+// kernel), k_trace_mfma_tiled (every other scene), k_mode_r_mfma (Mode R), k_trace_mfma (round 1's K = 64 kernel, the A/B reference).
+// Order of the file: the K = 64 form on v_mfma_f32_32x32x16_bf16 (the derivation; k_trace_mfma only), its 16x16x32 variant (A/B reference
+// for faces), the K = 32 form on v_mfma_f32_16x16x32_bf16 that every default kernel runs, the pair list, the kernels.
 // Part of rt3_device.hip (one translation unit, gfx950 only); included from there, in this order.
 #pragma once
 
@@ -212,7 +215,7 @@ __device__ __forceinline__ void mfma_flush(uint32_t nz, uint32_t n_blocks, const
     while (cand_next(it, bm, row)) eval(row);
 }
 // ------------------------------------------------------------------------------------------------------
-// The same filter on v_mfma_f32_16x16x32_bf16 — the form the tiled kernels and k_mode_r_mfma run
+// The same K = 64 filter on v_mfma_f32_16x16x32_bf16 (round 2's first step away from 32x32x16; -DRT3_FACE_K32=0 still selects it for faces)
 // ------------------------------------------------------------------------------------------------------
 // Under this load the chip is clock-limited, and it holds a higher clock on the 16x16x32 shape: tools/ubench_mfma_shape.hip — the
 // scan's instruction mix (4 ds_read_b128 + K = 64 of MFMA + 32 v_alignbit per 32 rows x 64 rays, four waves per SIMD, random operands) —
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma32(const TraceArgs A, const u
     if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, iters * n_blocks * 8ull); atomicAdd(A.cast_counter + 2, exact); }
 }
 
-// Any scene: faces (through their bounding spheres) and spheres, streamed through LDS in tiles of 512 rows.  The 16 waves of the
+// Any scene: faces (through their bounding spheres) and spheres, streamed through LDS in 64-KiB tiles of 1024 rows.  The 16 waves of the
 // workgroup move through the tiles together (two barriers per tile); candidates go through the pair list above, the exact tests
 // gather their records from global memory, all 64 lanes at a time.
 // REF: RT3_FLAG_REFERENCE_PRIMARY (camera at the origin, no lens: checked by the host).
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
         LaneRay ray = { P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, REF && P.depth == 0 };
         float ux = ray.dx, uy = ray.dy, uz = ray.dz;                            // what the filter sees: always a unit direction
         if (REF && ray.literal) { const float inv = 1.0f / __builtin_sqrtf(dot3(ux, uy, uz, ux, uy, uz)); ux = ux * inv; uy = uy * inv; uz = uz * inv; }
-        RayOperands16 R;                                                        // faces: K = 64
+        RayOperands16 R;                                                        // (faces in the K = 64 form: -DRT3_FACE_K32=0 only)
         RayOperands32 R32;                                                      // spheres: K = 32, coordinates about the filter centre
 #if RT3_FACE_K32
         if (HAS_TRI) build_ray_operands32(ray.ox - A.tcx, ray.oy - A.tcy, ray.oz - A.tcz, ux, uy, uz, alive, R32);
