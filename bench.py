@@ -51,13 +51,18 @@ MODE_R_REFERENCE_CPU_S = 60.2        # SequentialRenderer (the reference's own C
 
 
 def source_fingerprint():
-    """SHA-256 (first 16 hex digits) of the kernel sources: a committed profile only speaks for the build it was made from."""
+    """SHA-256 (first 16 hex digits) of the kernel sources with comments and white space removed: a committed profile only speaks for
+    the code it was made from (and keeps speaking for it when a comment changes)."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "raytracer-3_amd", "csrc")
+    strip = re.compile(r'//[^\n]*|/\*.*?\*/|("(?:\\.|[^"\\])*")', re.S)        # comments go, string literals stay
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".hpp", ".cpp")):
+            text = open(os.path.join(d, name), "r", encoding="utf-8", errors="replace").read()
+            text = strip.sub(lambda m: m.group(1) or " ", text)
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            h.update("".join(text.split()).encode())
     return h.hexdigest()[:16]
 
 
