@@ -29,6 +29,30 @@ def test_bench_refuses_a_world_size_that_does_not_match():
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stdout + p.stderr)
 
 
+def test_counter_provenance_follows_the_kernel_code_not_its_comments(tmp_path, monkeypatch):
+    """bench.py reports hardware-counter figures from profiles/ only for the kernel code they were collected on: the fingerprint must
+    change with the code and stay put when a comment or the layout changes; a stale profile yields nulls with the reason."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    src = tmp_path / "raytracer-3_amd" / "csrc"
+    src.mkdir(parents=True)
+    (src / "k.hip").write_text('__global__ void k(float* p) { p[0] = 1.0f; /* one */ asm("s_nop 0 // not a comment"); }\n')
+    monkeypatch.setattr(B, "ROOT", str(tmp_path))
+    a = B.source_fingerprint()
+    (src / "k.hip").write_text('// a new comment\n__global__ void k(float* p)\n{\n    p[0] = 1.0f;   /* two */\n    asm("s_nop 0 // not a comment");\n}\n')
+    assert B.source_fingerprint() == a
+    (src / "k.hip").write_text('__global__ void k(float* p) { p[0] = 2.0f; asm("s_nop 0 // not a comment"); }\n')
+    assert B.source_fingerprint() != a
+    (src / "k.hip").write_text('__global__ void k(float* p) { p[0] = 1.0f; asm("s_nop 1 // not a comment"); }\n')
+    assert B.source_fingerprint() != a                          # string literals (inline asm) are code
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / B.PMC_PROFILE).write_text(json.dumps({"_source_fingerprint": "0123456789abcdef"}))
+    traffic, why, valu = B.counters_from_profile(B.source_fingerprint())
+    assert traffic is None and valu is None and "stale" in why
+
+
 @pytest.mark.gpu
 def test_bench_line_has_every_field_of_the_contract():
     p = run_bench("--spp", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1")
