@@ -27,6 +27,18 @@
 extern "C" {
 #endif
 
+/* ABI version of this header: bumped whenever a wire struct changes size or meaning.  A host compares it with what the library
+ * it loaded reports before it passes any struct (rt3_stats grew from 56 to 64 bytes between versions 1 and 2; rt3_get_stats writes
+ * sizeof(rt3_stats) bytes of THIS version).  History: 1 = round 1; 2 = + mfma_instructions / exact_tests in rt3_stats, progressive
+ * accumulation, rt3_gather_rows; 3 = + rt3_abi_version itself, one stream convention (below). */
+#define RT3_ABI_VERSION 3u
+uint32_t rt3_abi_version(void);
+
+/* Stream convention of every entry point that takes a `stream` (a hipStream_t): the work is queued on that stream; NULL means the
+ * CONTEXT'S OWN stream (rt3_stream()), never the legacy default stream.  Calls on one context are ordered with each other whatever
+ * streams they name: a render that continues, overwrites or reads the accumulation waits (on the device) for the event the previous
+ * render recorded, rt3_accum_download / rt3_accum_upload wait for it on the host. */
+
 #define RT3_E_ARG     (-1)   /* bad argument */
 #define RT3_E_DEVICE  (-2)   /* HIP runtime / device failure (includes "no device") */
 #define RT3_E_IO      (-3)   /* file could not be opened / parsed */
@@ -159,13 +171,13 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
  * (0xFF | B<<8 | G<<16 | R<<24, row 0 = top; SequentialRenderer.cpp:297).  All rows are written; row h-1
  * follows the GLSL twin (raytracer_v3.glsl:193-196) because the CPU loop never writes it. */
 int rt3_render(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint32_t height, uint32_t* out_pixels);
-/* Mode R, asynchronous on `stream` (a hipStream_t, may be NULL), device output buffer of w*h words. */
+/* Mode R, asynchronous on `stream` (a hipStream_t; NULL = the context's own stream), device output buffer of w*h words. */
 int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint32_t height,
                       void* d_out_pixels, void* stream);
 
 /* Mode X, synchronous, host output of rt3_rows_owned(params)*width words (compact tile rows). */
 int rt3_render_path(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* params, uint32_t* out_pixels);
-/* Mode X, asynchronous on `stream`, device output. */
+/* Mode X, asynchronous on `stream` (NULL = the context's own stream), device output. */
 int rt3_render_path_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* params,
                            void* d_out_pixels, void* stream);
 
@@ -248,14 +260,15 @@ void     rt3_camera_look_at(rt3_camera* cam, const float from[3], const float at
 uint64_t rt3_frame_ppm_bytes(const uint32_t* pixels, uint32_t width, uint32_t height, uint8_t* out, uint64_t cap);
 int      rt3_frame_to_ppm(const uint32_t* pixels, uint32_t width, uint32_t height, const char* path);
 
-/* Benchmark scenes (build-owned).  Each returns the sphere count written (<= cap) or, with
- * NULL outputs, the count required.  All randomness comes from the reference's hash RNG
+/* Benchmark scenes (build-owned).  Each returns the sphere count of the scene — the count REQUIRED, whatever
+ * cap is (snprintf convention) — and writes at most cap spheres; NULL outputs write nothing.  All randomness comes from the reference's hash RNG
  * (src/lib/shaders/random_v1.glsl:22-52) keyed by (seed, slot, dimension). */
 uint32_t rt3_scene_three_spheres(float* center_radius, rt3_material* materials, uint32_t cap);
 uint32_t rt3_scene_weekend(uint32_t seed, float* center_radius, rt3_material* materials, uint32_t cap);
 uint32_t rt3_scene_stress(uint32_t n, uint32_t seed, float* center_radius, rt3_material* materials, uint32_t cap);
 /* Cornell-style box tessellated into triangles (grid x grid quads per wall) with one emissive quad.
- * Returns face count; vertices = 3 per face (unindexed).  NULL outputs -> counts only. */
+ * Returns the scene's face count (required, as above; at most cap_faces are written); vertices = 3 per face (unindexed).
+ * NULL outputs -> counts only. */
 uint32_t rt3_scene_cornell(uint32_t grid, rt3_gface* faces, float* vertices_xyzw, rt3_material* face_materials,
                            uint32_t cap_faces);
 

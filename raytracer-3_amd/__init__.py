@@ -74,7 +74,9 @@ EXPORTS = [
     "rt3_mesh_begin", "rt3_mesh_put", "rt3_mesh_sphere", "rt3_mesh_commit", "rt3_mesh_download",
     "rt3_render_path_range", "rt3_render_path_range_device", "rt3_accum_download", "rt3_accum_upload", "rt3_gather_rows",
     "rt3_stream", "rt3_synchronize", "rt3_device_alloc_words", "rt3_device_free", "rt3_device_read_words", "rt3_debug_force_brute",
+    "rt3_abi_version",
 ]
+ABI_VERSION = 3          # RT3_ABI_VERSION of include/rt3.h these bindings (the STATS / PARAMS struct layouts below) were written against
 
 _lib = None
 
@@ -125,11 +127,15 @@ def lib():
         "rt3_gather_rows": (i32, [vp, vp, vp, vp, vp, vp]), "rt3_stream": (vp, [vp]), "rt3_synchronize": (i32, [vp]),
         "rt3_device_alloc_words": (vp, [vp, u64]), "rt3_device_free": (None, [vp, vp]),
         "rt3_device_read_words": (i32, [vp, vp, u64, vp]), "rt3_debug_force_brute": (i32, [vp, i32]),
+        "rt3_abi_version": (u32, []),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    if L.rt3_abi_version() != ABI_VERSION:
+        raise Fatal("%s reports ABI version %d, these bindings were written against %d (include/rt3.h: RT3_ABI_VERSION)"
+                    % (LIB_PATH, L.rt3_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

@@ -79,6 +79,7 @@ struct rt3_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;              // per dominant-kernel launch
     uint32_t ev_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipEvent_t ev_acc = nullptr; bool ev_acc_recorded = false;      // end of the last Mode-X render: what the next user of d_rad / d_accum waits for
     hipStream_t last_stream = nullptr;
     uint64_t last_samples = 0;
     bool last_was_path = false;
@@ -324,6 +325,8 @@ int check_params(rt3_ctx* ctx, const rt3_params* p) {
 
 extern "C" {
 
+uint32_t rt3_abi_version(void) { return RT3_ABI_VERSION; }
+
 uint32_t rt3_rows_owned(const rt3_params* p) {
     uint32_t n = 0;
     for (uint32_t y = 0; y < p->height; y++) n += row_owned(p, y) ? 1u : 0u;
@@ -349,7 +352,7 @@ rt3_ctx* rt3_create(int device_id) {
     hipDeviceProp_t prop;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
         (e = hipStreamCreate(&ctx->stream)) != hipSuccess || (e = hipEventCreate(&ctx->ev_begin)) != hipSuccess ||
-        (e = hipEventCreate(&ctx->ev_end)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_end)) != hipSuccess || (e = hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc((void**)&ctx->d_work, 64)) != hipSuccess || (e = hipMalloc((void**)&ctx->d_casts, 128)) != hipSuccess) {
         g_create_error = std::string("rt3_create: ") + hipGetErrorString(e);
         delete ctx;
@@ -369,6 +372,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->ev_acc) (void)hipEventDestroy(ctx->ev_acc);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -473,6 +477,16 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
                        ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
                        ctx->d_tri_frag, n_frag_rows, (const uint32_t*)ctx->d_box, 1.0f);
     RT3_HIP(hipGetLastError());
+    // Mode R's rays all start at the world origin, the path tracer's mostly ON the scene: the filter's margin eps (|C - c|^2 + r^2 +
+    // |o - c|^2) is smallest about the point half-way to the mesh here and about the mesh's own centre there.  Mode R therefore keeps
+    // fragments of its own, built here by the same kernel (with centre_scale 0.5 it writes nothing else) while the merged entity
+    // buffers are known to be the ones these faces came from: a render never reads d_gfaces / d_verts, so an rt3_mesh_begin without a
+    // commit leaves the committed scene renderable.
+    RT3_HIP(hipMalloc((void**)&ctx->d_tri_frag_r, (size_t)n_frag_rows * 8 * sizeof(u32x4)));
+    hipLaunchKernelGGL(k_commit_mesh, dim3((n_frag_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, ctx->d_gfaces, ctx->d_verts, n, n_pad,
+                       ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
+                       (u32x4*)ctx->d_tri_frag_r, n_frag_rows, (const uint32_t*)ctx->d_box, 0.5f);
+    RT3_HIP(hipGetLastError());
     uint32_t err = 0, box[6];
     RT3_HIP(hipMemcpyAsync(&err, ctx->d_error, 4, hipMemcpyDeviceToHost, ctx->stream));
     RT3_HIP(hipMemcpyAsync(box, ctx->d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
@@ -570,7 +584,7 @@ int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint3
     if (!cam || !d_out) return fail(ctx, RT3_E_ARG, "cam / d_out_pixels is NULL");
     if (width < 2 || height < 2 || (uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RT3_E_ARG, "bad frame size");
     RT3_HIP(hipSetDevice(ctx->device));
-    hipStream_t stream = (hipStream_t)stream_;
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;     // rt3.h: NULL = the context's own stream
     ctx->rendered = false;                                          // stats are valid again once every launch below has been issued
     ctx->ev_used = 0;
     hipEvent_t a, b;
@@ -585,18 +599,7 @@ int rt3_render_device(rt3_ctx* ctx, const rt3_camera* cam, uint32_t width, uint3
         int per_cu = 0;
         if ((rc = blocks_per_cu(ctx, (const void*)k_mode_r_mfma, kMB, kTiledLdsBytes, &per_cu))) return rc;
         if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "k_mode_r_mfma does not fit on a CU");
-        // Mode R's rays all start at the world origin, the path tracer's mostly ON the scene: the filter's margin eps (|C - c|^2 + r^2 +
-        // |o - c|^2) is smallest about the point half-way to the mesh here and about the mesh's own centre there.  Mode R therefore keeps
-        // fragments of its own, built at its first render after a commit by the same kernel (in that mode it writes nothing else).
-        if (!ctx->d_tri_frag_r) {
-            const uint32_t n = ctx->n_faces, n_pad = (n + 3u) / 4u * 4u, n_frag_rows = (n + 31u) / 32u * 32u;
-            RT3_HIP(hipMalloc((void**)&ctx->d_tri_frag_r, (size_t)n_frag_rows * 8 * sizeof(u32x4)));
-            hipLaunchKernelGGL(k_commit_mesh, dim3((n_frag_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, ctx->d_gfaces, ctx->d_verts, n, n_pad,
-                               ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
-                               (u32x4*)ctx->d_tri_frag_r, n_frag_rows, (const uint32_t*)ctx->d_box, 0.5f);
-            RT3_HIP(hipGetLastError());
-            RT3_HIP(hipStreamSynchronize(stream));                  // once per mesh: a later render may come on another stream
-        }
+        if (!ctx->d_tri_frag_r) return fail(ctx, RT3_E_STATE, "internal: the committed mesh has no Mode-R fragments");     // (built by rt3_mesh_commit)
     }
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
     RT3_HIP(hipEventRecord(a, stream));
@@ -646,7 +649,10 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     if (ref && ctx->n_sph != 0) return fail(ctx, RT3_E_ARG, "RT3_FLAG_REFERENCE_PRIMARY needs a triangle-only scene");
     if (ctx->n_faces >= (1u << kPairLaneShift) - 32u || ctx->n_sph >= (1u << kPairLaneShift) - 32u) return fail(ctx, RT3_E_ARG, "too many primitives");
     RT3_HIP(hipSetDevice(ctx->device));
-    hipStream_t stream = (hipStream_t)stream_;
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;     // rt3.h: NULL = the context's own stream
+    // d_rad, d_accum and the counters belong to the context, not to a stream: whatever stream the previous render ran on, this one
+    // starts behind it (a wait on the device; nothing if it is the same stream)
+    if (ctx->ev_acc_recorded) RT3_HIP(hipStreamWaitEvent(stream, ctx->ev_acc, 0));
 
     const uint32_t rows = rt3_rows_owned(p);
     const uint32_t npix = rows * p->width;
@@ -663,6 +669,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
         RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 64, stream));
         RT3_HIP(hipEventRecord(ctx->ev_end, stream));
+        RT3_HIP(hipEventRecord(ctx->ev_acc, stream)); ctx->ev_acc_recorded = true;
         ctx->last_stream = stream; ctx->last_samples = 0; ctx->last_was_path = true; ctx->rendered = true;
         ctx->acc_valid = true; ctx->acc_params = *p; ctx->acc_cam = *cam; ctx->acc_done = sample_begin + sample_count; ctx->acc_npix = 0;
         return 0;
@@ -792,6 +799,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
                        ctx->d_accum, npix, sample_begin + sample_count, p->flags, (uint32_t*)d_out);
     RT3_HIP(hipGetLastError());
     RT3_HIP(hipEventRecord(ctx->ev_end, stream));
+    RT3_HIP(hipEventRecord(ctx->ev_acc, stream)); ctx->ev_acc_recorded = true;
     ctx->last_stream = stream;
     ctx->last_samples = (uint64_t)npix * sample_count;
     ctx->last_was_path = true;
@@ -832,8 +840,7 @@ int rt3_accum_download(rt3_ctx* ctx, float* sum, float* sum_sq, uint32_t* sample
     if (!ctx) return RT3_E_ARG;
     if (!ctx->acc_valid) return fail(ctx, RT3_E_STATE, "no accumulation on this context");
     RT3_HIP(hipSetDevice(ctx->device));
-    if (ctx->last_stream != ctx->stream) RT3_HIP(hipStreamSynchronize(ctx->last_stream));   // the render may run on the caller's stream
-    RT3_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ev_acc_recorded) RT3_HIP(hipEventSynchronize(ctx->ev_acc));        // the render may have run on a caller's stream (which may be gone by now)
     const size_t bytes = (size_t)ctx->acc_npix * sizeof(float4);
     if (sum && bytes) RT3_HIP(hipMemcpy(sum, ctx->d_accum, bytes, hipMemcpyDeviceToHost));
     if (sum_sq) {
@@ -855,6 +862,7 @@ int rt3_accum_upload(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, c
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t npix = rt3_rows_owned(p) * p->width;
     ctx->acc_valid = false;
+    if (ctx->ev_acc_recorded) RT3_HIP(hipEventSynchronize(ctx->ev_acc));        // a render still in flight reads and writes what is overwritten here
     if (npix) {
         if ((rc = ensure(ctx, &ctx->d_accum, &ctx->accum_entries, (size_t)npix))) return rc;
         RT3_HIP(hipMemcpy(ctx->d_accum, sum, (size_t)npix * sizeof(float4), hipMemcpyHostToDevice));

@@ -34,8 +34,8 @@ struct DataBlock { std::string path; };                                // every 
 class Parser {
 public:
     Parser(const std::string& text, const std::string& name, const std::string& dir, std::map<std::string, DataBlock>& data,
-           std::map<std::string, std::map<std::string, Value>>& fields, std::vector<RenderEntity*>& out)
-        : src(text), file(name), base_dir(dir), data_blocks(data), known(fields), entities(out) { advance(); }
+           std::map<std::string, std::map<std::string, Value>>& fields, std::vector<RenderEntity*>& out, int depth = 0)
+        : src(text), file(name), base_dir(dir), include_depth(depth), data_blocks(data), known(fields), entities(out) { advance(); }
 
     void parse_toplevel() {
         while (tok.kind != T::End) {
@@ -55,6 +55,14 @@ private:
     std::string src, file, base_dir;
     size_t pos = 0;
     int line = 1;
+    int include_depth = 0;                                            // files above this one in the #include chain
+    int nesting = 0;                                                  // recursion depth of the expression parser
+    static constexpr int kMaxIncludeDepth = 32, kMaxNesting = 200;    // found by the sanitizer build: a file that includes itself, 5000 '(' in a row
+    struct Nest {                                                     // every recursive descent step holds one
+        Parser& p;
+        explicit Nest(Parser& q) : p(q) { if (++p.nesting > kMaxNesting) p.fail("expression nested deeper than " + std::to_string(kMaxNesting) + " levels"); }
+        ~Nest() { --p.nesting; }
+    };
     Token tok;
     std::map<std::string, DataBlock>& data_blocks;
     std::map<std::string, std::map<std::string, Value>>& known;       // entity id (or "global") -> field -> value
@@ -87,7 +95,8 @@ private:
                 if (!in.is_open()) fail("cannot open included file '" + inc + "'");
                 std::stringstream ss; ss << in.rdbuf();
                 const size_t slash = inc.find_last_of('/');
-                Parser sub(ss.str(), inc, slash == std::string::npos ? "" : inc.substr(0, slash + 1), data_blocks, known, entities);
+                if (include_depth >= kMaxIncludeDepth) fail("#include nested deeper than " + std::to_string(kMaxIncludeDepth) + " files (does '" + inc + "' include itself?)");
+                Parser sub(ss.str(), inc, slash == std::string::npos ? "" : inc.substr(0, slash + 1), data_blocks, known, entities, include_depth + 1);
                 sub.parse_toplevel();                                             // conceptually pasted in place
             } else return;
         }
@@ -184,6 +193,7 @@ private:
 
     // ------------------------------------------------------------------ expressions (C precedence: unary, * / %, + -)
     Value primary() {
+        const Nest guard(*this);
         if (is_punct("(")) {
             advance();
             if (tok.kind == T::Id && (tok.text == "bool" || tok.text == "int" || tok.text == "uint" || tok.text == "float" || tok.text == "vec3")) {
@@ -228,6 +238,7 @@ private:
         fail("expected an expression, got '" + tok.text + "'");
     }
     Value unary() {
+        const Nest guard(*this);
         if (is_punct("-")) { advance(); Value v = unary(); if (v.kind == Value::Vec3) return Value::vec(-v.v[0], -v.v[1], -v.v[2]); v.s = -v.s; if (v.kind == Value::Uint) v.kind = Value::Int; return v; }
         if (is_punct("+")) { advance(); return unary(); }
         if (is_punct("!")) { advance(); return Value::scalar(Value::Bool, unary().num() == 0.0); }

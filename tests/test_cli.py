@@ -31,7 +31,8 @@ def test_help_exits_zero_and_lists_reference_options():
     assert run("--help")[0] == 0
 
 
-@pytest.mark.parametrize("args,msg", [
+# parse_cli's error table (src/Main.cpp:132,146,167-176,210,233); tests/test_sanitizers.py runs the same rows through the ASan/UBSan build
+USAGE_ERRORS = [
     ((), "No output path given."),
     (("-W",), "-W has no value."),
     (("--width", "-H", "3", "o.ppm"), "--width has no value."),
@@ -40,7 +41,10 @@ def test_help_exits_zero_and_lists_reference_options():
     (("-H", "99999999999999999999", "o"), "Height too large '99999999999999999999'"),
     (("-W", "4294967296", "o"), "Width too large '4294967296'"),
     (("--bogus", "o"), "Unknown option '--bogus'"),
-])
+]
+
+
+@pytest.mark.parametrize("args,msg", USAGE_ERRORS)
 def test_usage_errors_return_minus_one(args, msg):
     rc, out, err = run(*args)
     assert rc == -1 and msg in err

@@ -47,8 +47,7 @@ def test_sample_scene_parses(tmp_path):
 
 
 def test_expressions_and_whitespace_rule(tmp_path):
-    text = """global { float a: 2 + 3 * 4; float b: (2 + 3) * 4; int c: 7 / 2; float d: 7.0 / 2; float e: -(1 + 1) - -3; float f: 10 % 4; }
-    entities { triangle t { p1: global.a - 1 global.b -global.c; p2: 1 -2 3; p3: 1 - 2 3 4.5; color: sqrt(4) 0 0; } }"""
+    text = EXPRESSIONS
     rc, out, err = dump(tmp_path, text)
     assert rc == 0, err
     # `a -b` starts a new vec3 component, `a - b` and `a-b` subtract
@@ -63,7 +62,7 @@ def test_include_and_extern(tmp_path):
     assert out.strip() == "object faces=2 vertices=4 center=(0,0,-5) scale=2 color=(1,1,0)"
 
 
-@pytest.mark.parametrize("text,msg", [
+SCENE_ERRORS = [
     ("entities { cube c { } }", "unknown entity type 'cube'"),
     ("entities { sphere s { center: 0 0 -1; } }", "needs 'center' and 'radius'"),
     ("entities { triangle t { p1: 0 0 0; p2: 1 0 0; color: 1 0 0; } }", "lacks 'p3'"),
@@ -74,7 +73,12 @@ def test_include_and_extern(tmp_path):
     ('@error "stop here" entities { }', "@error: stop here"),
     ("entities { sphere a { center: 0 0 0; radius: 1 } }", "expected"),
     ("/* never closed", "unterminated comment"),
-])
+]
+EXPRESSIONS = """global { float a: 2 + 3 * 4; float b: (2 + 3) * 4; int c: 7 / 2; float d: 7.0 / 2; float e: -(1 + 1) - -3; float f: 10 % 4; }
+    entities { triangle t { p1: global.a - 1 global.b -global.c; p2: 1 -2 3; p3: 1 - 2 3 4.5; color: sqrt(4) 0 0; } }"""
+
+
+@pytest.mark.parametrize("text,msg", SCENE_ERRORS)
 def test_errors_are_fatal_with_file_and_line(tmp_path, text, msg):
     rc, out, err = dump(tmp_path, text)
     assert rc == -1 and msg in err and "s.scene:" in err

@@ -1,0 +1,49 @@
+// device_stubs.cpp — the device half of the C ABI (raytracer-3_amd/csrc/rt3_device.hip) as "no device" stubs, for the SANITIZER BUILD ONLY
+// (make -C raytracer-3_amd asan): the host code under test — rt3_host.cpp, SceneParser.cpp, HostApi.cpp, Main.cpp — is compiled with g++
+// -fsanitize=address,undefined and linked against these instead of librt3hip.so, so that it runs on a machine without a GPU and without the
+// HIP runtime inside the sanitizer.  Nothing in the product links this file; every entry point fails the way the library does when no
+// device is present (rt3_create returns NULL, the rest RT3_E_DEVICE).
+#include "rt3.h"
+
+extern "C" {
+uint32_t rt3_abi_version(void) { return RT3_ABI_VERSION; }
+rt3_ctx* rt3_create(int) { return nullptr; }
+void rt3_destroy(rt3_ctx*) {}
+const char* rt3_last_error(const rt3_ctx*) { return "sanitizer build: no HIP device (tools/asan/device_stubs.cpp)"; }
+int rt3_set_sample_storage_cap(rt3_ctx*, uint64_t) { return RT3_E_DEVICE; }
+int rt3_set_mesh(rt3_ctx*, const rt3_gface*, uint32_t, const float*, uint32_t, const rt3_material*) { return RT3_E_DEVICE; }
+int rt3_mesh_begin(rt3_ctx*, uint32_t, uint32_t) { return RT3_E_DEVICE; }
+int rt3_mesh_put(rt3_ctx*, const rt3_gface*, uint32_t, const float*, uint32_t, uint32_t, uint32_t) { return RT3_E_DEVICE; }
+int rt3_mesh_sphere(rt3_ctx*, const float*, float, uint32_t, uint32_t, const float*, uint32_t, uint32_t) { return RT3_E_DEVICE; }
+int rt3_mesh_commit(rt3_ctx*, const rt3_material*) { return RT3_E_DEVICE; }
+int rt3_mesh_download(rt3_ctx*, rt3_gface*, float*) { return RT3_E_DEVICE; }
+int rt3_set_spheres(rt3_ctx*, const float*, const rt3_material*, uint32_t) { return RT3_E_DEVICE; }
+int rt3_render(rt3_ctx*, const rt3_camera*, uint32_t, uint32_t, uint32_t*) { return RT3_E_DEVICE; }
+int rt3_render_device(rt3_ctx*, const rt3_camera*, uint32_t, uint32_t, void*, void*) { return RT3_E_DEVICE; }
+int rt3_render_path(rt3_ctx*, const rt3_camera*, const rt3_params*, uint32_t*) { return RT3_E_DEVICE; }
+int rt3_render_path_device(rt3_ctx*, const rt3_camera*, const rt3_params*, void*, void*) { return RT3_E_DEVICE; }
+int rt3_render_path_range(rt3_ctx*, const rt3_camera*, const rt3_params*, uint32_t, uint32_t, uint32_t*) { return RT3_E_DEVICE; }
+int rt3_render_path_range_device(rt3_ctx*, const rt3_camera*, const rt3_params*, uint32_t, uint32_t, void*, void*) { return RT3_E_DEVICE; }
+int rt3_accum_download(rt3_ctx*, float*, float*, uint32_t*) { return RT3_E_DEVICE; }
+int rt3_accum_upload(rt3_ctx*, const rt3_camera*, const rt3_params*, const float*, const float*, uint32_t) { return RT3_E_DEVICE; }
+int rt3_gather_rows(rt3_ctx*, void*, rt3_ctx*, const void*, const rt3_params*, void*) { return RT3_E_DEVICE; }
+void* rt3_stream(rt3_ctx*) { return nullptr; }
+int rt3_synchronize(rt3_ctx*) { return RT3_E_DEVICE; }
+void* rt3_device_alloc_words(rt3_ctx*, uint64_t) { return nullptr; }
+void rt3_device_free(rt3_ctx*, void*) {}
+int rt3_device_read_words(rt3_ctx*, const void*, uint64_t, uint32_t*) { return RT3_E_DEVICE; }
+int rt3_get_stats(rt3_ctx*, rt3_stats*) { return RT3_E_DEVICE; }
+int rt3_debug_force_plain_mode_r(rt3_ctx*, int) { return RT3_E_DEVICE; }
+int rt3_debug_force_brute(rt3_ctx*, int) { return RT3_E_DEVICE; }
+int rt3_debug_arith(rt3_ctx*, const float*, const float*, uint32_t, float*, float*, float*, float*, float*, float*, uint32_t*) { return RT3_E_DEVICE; }
+// (rt3_rows_owned / rt3_row_of_local are pure host arithmetic that happens to live in rt3_device.hip)
+uint32_t rt3_rows_owned(const rt3_params* p) {
+    uint32_t n = 0;
+    for (uint32_t y = 0; y < p->height; y++) n += (p->tile_count <= 1 || ((y / p->tile_rows) % p->tile_count) == p->tile_index) ? 1u : 0u;
+    return n;
+}
+uint32_t rt3_row_of_local(const rt3_params* p, uint32_t local_row) {
+    if (p->tile_count <= 1) return local_row;
+    return ((local_row / p->tile_rows) * p->tile_count + p->tile_index) * p->tile_rows + local_row % p->tile_rows;
+}
+}
