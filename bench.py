@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads runs")
     ap.add_argument("--save-ppm", default="", help="rank 0 writes the last frame here")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks that ALL render on cuda:0 and gather over gloo through host memory: exercises this file's multi-rank control flow "
+                         "(sharding, gather, stat reduction, the JSON line) where only one GPU is present; its numbers are not a measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -260,11 +263,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    rehearsal = args.rehearse_on_one_gpu and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("RT3_BENCH_FORCE_DIST") == "1"     # the env knob rehearses the RCCL path on one GPU
     if use_dist:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev                        # where the reduced scalars live (gloo reduces host tensors)
 
     rt3 = importlib.import_module("raytracer-3_amd")
     W, H = args.width, args.height
@@ -278,13 +288,16 @@ def main():
                               lens_radius=0.05, tile_rows=TILE_ROWS, tile_index=i, tile_count=world) for i in range(world)]
     my = params[rank]
     shard = importlib.import_module("raytracer-3_amd.shard")
-    g = shard.FrameGatherer(rt3, params, rank, dev, force_collective=use_dist and world == 1, renderer=r)
+    g = shard.FrameGatherer(rt3, params, rank, dev, force_collective=use_dist and world == 1, renderer=r, stage_host=rehearsal)
     tile = g.tile
-    stream = torch.cuda.current_stream()
+    # One explicit stream for the render, the gather and everything torch queues around them: the C ABI is handed its handle (never NULL,
+    # which include/rt3.h defines as "the context's own stream"), RCCL orders its kernels behind torch's CURRENT stream, which is this one
+    stream = torch.cuda.Stream(device=dev)
 
     def step():
-        r.render_path_device(cam.c, my, tile.data_ptr(), stream.cuda_stream)
-        g.gather(stream.cuda_stream)           # N>1: ONE RCCL gather over xGMI (8.3 MB / N per peer); N=1: rt3_gather_rows on the same stream
+        with torch.cuda.stream(stream):
+            r.render_path_device(cam.c, my, tile.data_ptr(), stream.cuda_stream)
+            g.gather(stream.cuda_stream)       # N>1: ONE RCCL gather over xGMI (8.3 MB / N per peer); N=1: rt3_gather_rows on the same stream
 
     def sync():
         if use_dist:
@@ -302,8 +315,8 @@ def main():
     st = r.stats()                                                       # HIP events of the last step, on `stream`
     trace_ms, tests, casts, launches = st.trace_ms, st.prim_tests, st.ray_casts, st.launches
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    agg = torch.tensor([float(tests), float(casts), float(trace_ms)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    agg = torch.tensor([float(tests), float(casts), float(trace_ms)], dtype=torch.float64, device=red_dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg[:2], op=dist.ReduceOp.SUM)
@@ -349,7 +362,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "In-One-Weekend final random-spheres scene, %d spheres (scene seed %d), %dx%d, %d spp, "
                                    "depth %d, thin lens, gamma 2" % (len(cr), SCENE_SEED, W, H, args.spp, args.depth),
-                       "sharding": ("interleaved %d-row blocks over %d GPU(s), RCCL gather to rank 0" % (TILE_ROWS, world)) if use_dist else
+                       "sharding": ("REHEARSAL: %d ranks on ONE GPU, interleaved %d-row blocks, gloo gather through host memory — control flow only, not a "
+                                    "measurement" % (world, TILE_ROWS)) if rehearsal else
+                                   ("interleaved %d-row blocks over %d GPU(s), RCCL gather to rank 0" % (TILE_ROWS, world)) if use_dist else
                                    "one GPU, rows through rt3_gather_rows (device-to-device)"},
             "ray_casts": int(agg[1].item()), "prim_tests": int(agg[0].item()),
             "tests_per_s": round(agg[0].item() / (elapsed / args.steps), 1),

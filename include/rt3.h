@@ -30,7 +30,8 @@ extern "C" {
 /* ABI version of this header: bumped whenever a wire struct changes size or meaning.  A host compares it with what the library
  * it loaded reports before it passes any struct (rt3_stats grew from 56 to 64 bytes between versions 1 and 2; rt3_get_stats writes
  * sizeof(rt3_stats) bytes of THIS version).  History: 1 = round 1; 2 = + mfma_instructions / exact_tests in rt3_stats, progressive
- * accumulation, rt3_gather_rows; 3 = + rt3_abi_version itself, one stream convention (below). */
+ * accumulation, rt3_gather_rows; 3 = + rt3_abi_version itself, one stream convention (below),
+ * filter_tests / bound_tests in rt3_stats (80 bytes). */
 #define RT3_ABI_VERSION 3u
 uint32_t rt3_abi_version(void);
 
@@ -119,8 +120,12 @@ typedef struct rt3_stats {
     uint32_t n_spheres, n_faces;
     uint32_t mfma_flop_per_instruction;   /* 32768 (v_mfma_f32_32x32x16_bf16: k_trace_mfma) or 16384 (v_mfma_f32_16x16x32_bf16: tiled kernels) */
     uint64_t mfma_instructions;  /* bf16 MFMA wave-instructions issued by the candidate filter (0: VALU scan / brute force) */
-    uint64_t exact_tests;        /* (ray, primitive) pairs that survived the filter and went through the exact test
-                                    (counted by the tiled matrix-filter kernels; 0 elsewhere)                            */
+    uint64_t exact_tests;        /* (ray, primitive) pairs that survived the filter(s) and went through the exact test
+                                    (counted by the pair-list kernels; 0 elsewhere)                                      */
+    uint64_t filter_tests;       /* (ray, row) pairs the matrix filter evaluated = ray_casts * rows; a row is one primitive in the
+                                    flat filter and a group of primitives in the two-level filter, so this is what
+                                    the matrix cores executed, while prim_tests is the brute-force-equivalent count              */
+    uint64_t bound_tests;        /* two-level filter, faces: members of candidate groups checked against their own bounding sphere */
 } rt3_stats;
 
 typedef struct rt3_ctx rt3_ctx;
@@ -286,6 +291,9 @@ int      rt3_debug_force_plain_mode_r(rt3_ctx* ctx, int on);
  * UNFILTERED Mode-X kernel (every ray against every primitive in index order, no bounding spheres, no matrix cores) —
  * the on-GPU arbiter for the candidate filters.  Same effect: environment variable RT3_BRUTE=1. */
 int      rt3_debug_force_brute(rt3_ctx* ctx, int on);
+/* Debug switch (tests, A/B): non-zero makes the tiled matrix-filter kernel scan one row per primitive (the flat filter) instead of the
+ * two-level filter's group rows.  Same pixels.  Same effect: environment variable RT3_NO_GROUPS=1. */
+int      rt3_debug_force_flat_filter(rt3_ctx* ctx, int on);
 int      rt3_debug_arith(rt3_ctx* ctx, const float* a, const float* b, uint32_t n, float* div, float* sq, float* fm,
                          float* cs, float* sn, float* sk3, uint32_t* pk);
 

@@ -55,7 +55,7 @@ class rt3_stats(C.Structure):
     _fields_ = [("ray_casts", C.c_uint64), ("prim_tests", C.c_uint64), ("samples", C.c_uint64),
                 ("trace_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint32),
                 ("n_spheres", C.c_uint32), ("n_faces", C.c_uint32), ("mfma_flop_per_instruction", C.c_uint32), ("mfma_instructions", C.c_uint64),
-                ("exact_tests", C.c_uint64)]
+                ("exact_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("bound_tests", C.c_uint64)]
 
 
 class Fatal(RuntimeError):
@@ -74,7 +74,7 @@ EXPORTS = [
     "rt3_mesh_begin", "rt3_mesh_put", "rt3_mesh_sphere", "rt3_mesh_commit", "rt3_mesh_download",
     "rt3_render_path_range", "rt3_render_path_range_device", "rt3_accum_download", "rt3_accum_upload", "rt3_gather_rows",
     "rt3_stream", "rt3_synchronize", "rt3_device_alloc_words", "rt3_device_free", "rt3_device_read_words", "rt3_debug_force_brute",
-    "rt3_abi_version",
+    "rt3_abi_version", "rt3_debug_force_flat_filter",
 ]
 ABI_VERSION = 3          # RT3_ABI_VERSION of include/rt3.h these bindings (the STATS / PARAMS struct layouts below) were written against
 
@@ -127,7 +127,7 @@ def lib():
         "rt3_gather_rows": (i32, [vp, vp, vp, vp, vp, vp]), "rt3_stream": (vp, [vp]), "rt3_synchronize": (i32, [vp]),
         "rt3_device_alloc_words": (vp, [vp, u64]), "rt3_device_free": (None, [vp, vp]),
         "rt3_device_read_words": (i32, [vp, vp, u64, vp]), "rt3_debug_force_brute": (i32, [vp, i32]),
-        "rt3_abi_version": (u32, []),
+        "rt3_abi_version": (u32, []), "rt3_debug_force_flat_filter": (i32, [vp, i32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -568,6 +568,10 @@ class HipRenderer(Renderer):
     def force_brute(self, on):
         """Tests / fuzzers: the unfiltered Mode-X kernel (every ray against every primitive)."""
         self._check(lib().rt3_debug_force_brute(self._ctx, 1 if on else 0))
+
+    def force_flat_filter(self, on):
+        """Tests / A-B: the tiled matrix-filter kernel with one row per primitive instead of the two-level filter's group rows (same pixels)."""
+        self._check(lib().rt3_debug_force_flat_filter(self._ctx, 1 if on else 0))
 
     def render_path_device(self, camera_c, params, d_out_ptr, stream_ptr=None):
         """Asynchronous Mode X into a device buffer (e.g. a torch tensor's data_ptr()) on a HIP stream."""

@@ -59,6 +59,10 @@ struct rt3_ctx {
     uint32_t n_sph = 0;
     float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t n_direct = 0; uint32_t direct[4] = { 0, 0, 0, 0 }; float tri_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t* d_box = nullptr; uint32_t* d_tri_frag_r = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
+    // group rows of the two-level filter: faces in face order, spheres in the order of a spatial median split
+    u32x4* d_tri_gfrag = nullptr; uint32_t n_tri_groups = 0;
+    u32x4* d_sph_gfrag = nullptr; float4* d_sph_grp = nullptr; uint32_t* d_sph_perm = nullptr; uint32_t n_sph_groups = 0;
+
     // work buffers
     Rgb* d_rad = nullptr; size_t rad_entries = 0;
     float4* d_accum = nullptr; size_t accum_entries = 0;
@@ -69,6 +73,8 @@ struct rt3_ctx {
     uint64_t rad_cap_bytes = 16ull << 30;
     bool force_plain_mode_r = false;                                // tests: compare the two Mode-R kernels
     bool force_brute = false;                                       // tests / fuzzers: unfiltered Mode-X kernel
+    bool force_flat = false;                                        // tests / A-B: one filter row per primitive (no groups)
+    uint64_t last_filter_rows = 0;                                  // rows the matrix filter scanned per ray cast in the last Mode-X render
     // the accumulation a progressive render continues (rt3_render_path_range): what it belongs to and how far it got
     bool acc_valid = false; rt3_params acc_params{}; rt3_camera acc_cam{}; uint32_t acc_done = 0; uint32_t acc_npix = 0;
     // launch configuration per (kernel, dynamic LDS): max dynamic LDS attribute set, workgroups per CU
@@ -288,6 +294,44 @@ uint32_t sphere_direct_list(const float* center_radius, uint32_t n, const float 
     return count;
 }
 
+// Group order of the spheres for the two-level filter: a median split of the centres along the longest axis of their box,
+// repeated until a part holds at most `group` spheres; the left part of every split is a multiple of `group`, so that only the very last
+// group is short.  Consecutive runs of `group` entries of the result are the groups; 0xFFFFFFFF pads the last one.  Spheres on the `direct`
+// list (tested for every ray anyway) and spheres whose record is not finite (no exact test can accept them) stay out.
+// Any order is correct — the nearest-hit key carries the sphere's own index, and the minimum over the keys does not depend on the order the
+// pairs are tested in — a compact one keeps the groups' bounding spheres small.
+std::vector<uint32_t> sphere_group_order(const float* center_radius, uint32_t n, const uint32_t* direct, uint32_t n_direct, uint32_t group) {
+    std::vector<uint32_t> ids;
+    ids.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float* s = center_radius + 4 * (size_t)i;
+        if (is_direct(i, direct, n_direct) || !std::isfinite(s[0]) || !std::isfinite(s[1]) || !std::isfinite(s[2]) || !std::isfinite(s[3] * s[3])) continue;
+        ids.push_back(i);
+    }
+    struct Part { size_t begin, end; };
+    std::vector<Part> stack;
+    stack.push_back({ 0, ids.size() });
+    while (!stack.empty()) {
+        const Part part = stack.back();
+        stack.pop_back();
+        const size_t count = part.end - part.begin;
+        if (count <= group) continue;
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (size_t k = part.begin; k < part.end; k++)
+            for (int a = 0; a < 3; a++) { const float c = center_radius[4 * (size_t)ids[k] + a]; lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
+        int axis = 0;
+        for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+        size_t half = (count / 2 + group - 1) / group * group;
+        if (half >= count) half = count - group;                    // (count > group here)
+        std::nth_element(ids.begin() + part.begin, ids.begin() + part.begin + half, ids.begin() + part.end,
+                         [&](uint32_t x, uint32_t y) { return center_radius[4 * (size_t)x + axis] < center_radius[4 * (size_t)y + axis]; });
+        stack.push_back({ part.begin + half, part.end });
+        stack.push_back({ part.begin, part.begin + half });
+    }
+    ids.resize((ids.size() + group - 1) / group * group, 0xFFFFFFFFu);
+    return ids;
+}
+
 bool row_owned(const rt3_params* p, uint32_t y) {
     if (p->tile_count <= 1) return true;
     return ((y / p->tile_rows) % p->tile_count) == p->tile_index;
@@ -367,7 +411,8 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
-                     ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r };
+                     ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r,
+                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -444,9 +489,9 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
     for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in,
-                      (void**)&ctx->d_tri_frag_r })
+                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag })
         if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
-    ctx->n_faces = 0;
+    ctx->n_faces = 0; ctx->n_tri_groups = 0;
     if (n == 0) return 0;
     if (face_materials)
         for (uint32_t i = 0; i < n; i++)
@@ -487,6 +532,16 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
                        ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
                        (u32x4*)ctx->d_tri_frag_r, n_frag_rows, (const uint32_t*)ctx->d_box, 0.5f);
     RT3_HIP(hipGetLastError());
+    // rows of the two-level filter: the bounding sphere of every kGroup consecutive faces, from the faces' own bounds (meshes come in a
+    // coherent order: a tessellation emits neighbours one after the other)
+    ctx->n_tri_groups = (n + kGroup - 1u) / kGroup;
+    {
+        const uint32_t n_group_rows = (ctx->n_tri_groups + 31u) / 32u * 32u;
+        RT3_HIP(hipMalloc((void**)&ctx->d_tri_gfrag, (size_t)n_group_rows * 4 * sizeof(u32x4)));
+        hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_bound, n, kGroup,
+                           n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_gfrag);
+        RT3_HIP(hipGetLastError());
+    }
     uint32_t err = 0, box[6];
     RT3_HIP(hipMemcpyAsync(&err, ctx->d_error, 4, hipMemcpyDeviceToHost, ctx->stream));
     RT3_HIP(hipMemcpyAsync(box, ctx->d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
@@ -540,6 +595,24 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
     if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
         (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
         return rc;
+    // rows of the two-level filter: groups of kGroup spheres in the order of a spatial median split
+    {
+        const std::vector<uint32_t> order = sphere_group_order(center_radius, n, ctx->direct, ctx->n_direct, kGroup);
+        std::vector<float4> grp(order.size(), kPadSphere);
+        for (size_t k = 0; k < order.size(); k++) if (order[k] != 0xFFFFFFFFu) grp[k] = sph[order[k]];
+        if ((rc = upload(ctx, &ctx->d_sph_grp, grp)) || (rc = upload(ctx, &ctx->d_sph_perm, order))) return rc;
+        if (ctx->d_sph_gfrag) { RT3_HIP(hipFree(ctx->d_sph_gfrag)); ctx->d_sph_gfrag = nullptr; }
+        ctx->n_sph_groups = (uint32_t)(order.size() / kGroup);
+        if (ctx->n_sph_groups) {
+            const uint32_t n_group_rows = (ctx->n_sph_groups + 31u) / 32u * 32u;
+            RT3_HIP(hipMalloc((void**)&ctx->d_sph_gfrag, (size_t)n_group_rows * 4 * sizeof(u32x4)));
+            hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_sph_grp,
+                               (uint32_t)order.size(), kGroup, n_group_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2],
+                               ctx->d_sph_gfrag);
+            RT3_HIP(hipGetLastError());
+            RT3_HIP(hipStreamSynchronize(ctx->stream));             // a render may come on another stream
+        }
+    }
     ctx->n_sph = n;
     return 0;
 }
@@ -547,6 +620,12 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
 int rt3_debug_force_brute(rt3_ctx* ctx, int on) {
     if (!ctx) return RT3_E_ARG;
     ctx->force_brute = on != 0;
+    return 0;
+}
+
+int rt3_debug_force_flat_filter(rt3_ctx* ctx, int on) {
+    if (!ctx) return RT3_E_ARG;
+    ctx->force_flat = on != 0;
     return 0;
 }
 
@@ -734,6 +813,10 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && !getenv("RT3_FORCE_TILED");   // (A/B knob)
     const bool single_k64 = mfma_single && getenv("RT3_MFMA_K64") != nullptr;
     const bool sph_lds = has_sph && ctx->n_sph <= kSphLdsMax;
+    const bool grouped = kGroup > 1 && !ctx->force_flat && !getenv("RT3_NO_GROUPS");
+    A.n_tri_rows = grouped ? ctx->n_tri_groups : ctx->n_faces;
+    A.n_sph_rows = grouped ? ctx->n_sph_groups : ctx->n_sph;
+    A.sph_grp = ctx->d_sph_grp; A.sph_perm = ctx->d_sph_perm;
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
     TraceKernel plain = nullptr;
     TiledKernel tiled = nullptr;
@@ -750,8 +833,14 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         block = kMB;
         kptr = single_k64 ? (const void*)k_trace_mfma : (const void*)k_trace_mfma32;
     } else if (use_mfma) {
-        tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
-                        : k_trace_mfma_tiled<false, true, false>;
+        // the two-level filter (rows = groups of kGroup primitives) unless RT3_NO_GROUPS=1 asks for the flat one (A/B reference, tests)
+        constexpr uint32_t G = kGroup;
+        if (grouped)
+            tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false, G, G> : (ref ? k_trace_mfma_tiled<true, false, true, G, 1> : k_trace_mfma_tiled<true, false, false, G, 1>))
+                            : k_trace_mfma_tiled<false, true, false, 1, G>;
+        else
+            tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
+                            : k_trace_mfma_tiled<false, true, false>;
         lds = kTraceTiledLdsBytes;
         block = kTB;
         kptr = (const void*)tiled;
@@ -786,7 +875,8 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         RT3_HIP(hipEventRecord(a, stream));
         if (mfma_single && single_k64) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
         else if (mfma_single) hipLaunchKernelGGL(k_trace_mfma32, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag32, mfma_blocks);
-        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kTB), lds, stream, A, (const u32x4*)ctx->d_tri_frag, (const u32x4*)ctx->d_sph_frag32);
+        else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kTB), lds, stream, A, (const u32x4*)(grouped ? ctx->d_tri_gfrag : ctx->d_tri_frag),
+                                           (const u32x4*)(grouped ? ctx->d_sph_gfrag : (u32x4*)ctx->d_sph_frag32));
         else hipLaunchKernelGGL(plain, dim3(grid), dim3(kBlock), lds, stream, A);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipEventRecord(b, stream));
@@ -804,6 +894,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     ctx->last_samples = (uint64_t)npix * sample_count;
     ctx->last_was_path = true;
     ctx->last_mfma16 = tiled != nullptr || (mfma_single && !single_k64);
+    ctx->last_filter_rows = tiled ? (uint64_t)A.n_tri_rows + A.n_sph_rows : mfma_single ? ctx->n_sph : 0;
     ctx->rendered = true;
     ctx->acc_valid = true; ctx->acc_params = *p; ctx->acc_cam = *cam; ctx->acc_done = sample_begin + sample_count; ctx->acc_npix = npix;
     return 0;
@@ -970,7 +1061,9 @@ int rt3_get_stats(rt3_ctx* ctx, rt3_stats* out) {
         out->mfma_flop_per_instruction = counters[1] ? (ctx->last_mfma16 ? 16384u : 32768u) : 0u;
 #ifndef RT3_PROFILE
         out->exact_tests = counters[2];
+        out->bound_tests = counters[3];
 #endif
+        out->filter_tests = counters[0] * ctx->last_filter_rows;
     } else {
         out->ray_casts = ctx->last_samples;
         out->prim_tests = ctx->last_samples * (uint64_t)ctx->n_faces;

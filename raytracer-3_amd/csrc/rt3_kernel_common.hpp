@@ -130,6 +130,11 @@ struct TraceArgs {
     // filter and cost the pair list 64 entries per ray cast each: they are tested directly, every lane its own ray, and their fragment
     // rows can never be candidates (sphere_direct_list in rt3_device.hip).  Matrix-filter kernels only.
     uint32_t n_direct; uint32_t direct[4];
+    // Two-level filter of k_trace_mfma_tiled: with a group size G > 1 a row of the matrix filter is the bounding sphere of G
+    // primitives.  Faces are grouped in face order (row g = faces [g G, (g + 1) G)); spheres in the order of a spatial median split
+    // (rt3_set_spheres): sph_grp holds their (cx, cy, cz, r^2) records in GROUP order, sph_perm the sphere index of each (0xFFFFFFFF: padding,
+    // and the direct spheres, which are not in any group).  *_rows: rows the pass scans (= primitives when G is 1).
+    const float4* sph_grp; const uint32_t* sph_perm; uint32_t n_sph_rows, n_tri_rows;
     uint32_t* work_counter;
     unsigned long long* cast_counter;
 };

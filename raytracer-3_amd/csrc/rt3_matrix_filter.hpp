@@ -548,9 +548,12 @@ __device__ __forceinline__ void test_all(uint32_t lane, const uint32_t* pairs, u
 // Pushes this lane's candidates of the tile just scanned (rows row0 ..) into the wave's list and tests 64 pairs whenever that many are
 // there; n_pairs (wave-uniform) carries the remainder to the next tile.  The words are mfma16_scan_tile's: bit 8 G + 4 h + j of word blk
 // is (ray lane 16 G + c, row 32 blk + 16 h + 4 g + j), with (g, c) the pushing lane's own position.
-template <uint32_t STRIDE = kMB, class Test>
+// GROUP > 1 (two-level filter): a row is a group of GROUP primitives and a pair expands into GROUP member tests, so a round
+// of the 64 lanes takes 64 / GROUP pairs — lane k tests member k % GROUP of pair k / GROUP — and `test` gets the member beside the pair.
+template <uint32_t STRIDE = kMB, uint32_t GROUP = 1, class Test>
 __device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
                                              uint32_t& n_pairs, Test&& test) {
+    constexpr uint32_t PER = 64u / GROUP;                           // pairs per round
     CandIter it = { nz, 0u, 0u, n_blocks };
     const uint32_t c = lane & 15u, g4 = (lane >> 4) * 4u;
     for (;;) {
@@ -563,13 +566,44 @@ __device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, con
         if (have) pairs[n_pairs + prefix_count(m)] = (ray_lane << kPairLaneShift) | row;
         n_pairs += (uint32_t)__popcll(m);
         __builtin_amdgcn_wave_barrier();
-        if (n_pairs >= 64u) {
-            n_pairs -= 64u;
-            test(pairs[n_pairs + lane], true);
+        if constexpr (GROUP == 1) {
+            if (n_pairs >= 64u) {
+                n_pairs -= 64u;
+                test(pairs[n_pairs + lane], true);
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (n_pairs >= PER) {
+            // rounds of member tests, software-pipelined: the gathers of the next round (member records from L2, the rays from their lanes) are
+            // in flight while this round computes — a round alone is all latency
+            n_pairs -= PER;
+            auto cur = test.fetch(pairs[n_pairs + lane / GROUP], true, lane % GROUP);
+            while (n_pairs >= PER) {
+                n_pairs -= PER;
+                auto nxt = test.fetch(pairs[n_pairs + lane / GROUP], true, lane % GROUP);
+                test.compute(cur);
+                __builtin_amdgcn_wave_barrier();
+                cur = nxt;
+            }
+            test.compute(cur);
             __builtin_amdgcn_wave_barrier();
         }
     }
 }
+// The rest of a group-pair list (fewer than 64 / GROUP pairs) at the end of a pass.
+template <uint32_t GROUP, class Test>
+__device__ __forceinline__ void test_all_groups(uint32_t lane, const uint32_t* pairs, uint32_t& n_pairs, Test&& test) {
+    constexpr uint32_t PER = 64u / GROUP;
+    while (n_pairs != 0u) {
+        const uint32_t take = n_pairs < PER ? n_pairs : PER;
+        n_pairs -= take;
+        const bool valid = lane / GROUP < take;
+        test.compute(test.fetch(valid ? pairs[n_pairs + lane / GROUP] : 0u, valid, lane % GROUP));
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// A member test in two halves, so that the loads of one round can be issued before the arithmetic of the previous one.
+template <class Fetch, class Compute> struct GroupTest { Fetch fetch; Compute compute; };
+template <class Fetch, class Compute> __device__ __forceinline__ GroupTest<Fetch, Compute> group_test_of(Fetch f, Compute c) { return GroupTest<Fetch, Compute>{ f, c }; }
 
 // Sphere scenes of <= 512 spheres: everything the loop touches lives in LDS, waves never synchronise after the prologue.
 __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32x4* __restrict__ frags, uint32_t n_blocks) {
@@ -796,7 +830,7 @@ constexpr uint32_t kTB = RT3_TILED_TB;                              // threads p
 constexpr uint32_t kTileLoads = RT3_TILE_LOADS;                     // 16-byte vectors per thread and tile: the fragment tile is kTB * kTileLoads * 16 bytes
 constexpr uint32_t kBmBlocks = RT3_BM_BLOCKS;                       // row blocks scanned before their candidate words are pushed (words: kBmBlocks * kTB * 4 bytes)
 constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;     // k_mode_r_mfma
-constexpr size_t kTraceTiledLdsBytes = (size_t)kTB * (kTileLoads * 16 + kBmBlocks * 4 + 8) + (size_t)(kTB / 64) * kPairCap * 4;
+constexpr size_t kTraceTiledLdsBytes = (size_t)kTB * (kTileLoads * 16 + kBmBlocks * 4 + 8) + (size_t)(kTB / 64) * kPairCap * 4 * 2;      // two pair lists per wave
 // One tile of fragments through the workgroup: [barrier] loads -> LDS stores [barrier].
 template <uint32_t TB = kMB, uint32_t LOADS = 4>
 __device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict__ src, uint32_t n_vec, uint32_t tid) {
@@ -808,15 +842,25 @@ __device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict
     for (uint32_t i = 0; i < LOADS; i++) { const uint32_t k = tid + i * TB; if (k < n_vec) s_frag[k] = v[i]; }
     __syncthreads();
 }
-template <bool HAS_TRI, bool HAS_SPH, bool REF>
+// GT / GS: group size of the faces' / spheres' rows (1: one row per primitive, the flat filter; > 1: the two-level filter of DESIGN.md 5.2e —
+// a row is the bounding sphere of G primitives, a candidate row expands into G member tests: for spheres the exact test itself, for faces
+// first the f32 test of the member's own bounding sphere (the vector-ALU kernels' scan arithmetic, 16-byte record) whose survivors are
+// compacted into a second pair list and get the reference's plane + three-edge test, 64 at a time).  Both must divide 64.
+#ifndef RT3_GROUP
+#define RT3_GROUP 8
+#endif
+constexpr uint32_t kGroup = RT3_GROUP;
+template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t GT = 1, uint32_t GS = 1>
 __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
+    static_assert(64 % GT == 0 && 64 % GS == 0, "group sizes must divide the wave");
     extern __shared__ u32x4 lds_dyn[];
     u32x4* s_frag = lds_dyn;                                                   // kTB * kTileLoads vectors: [16][4][64] at 1024 threads x 4
     uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + kTB * kTileLoads);   // [kBmBlocks][kTB] candidate words
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + kBmBlocks * kTB);   // [kTB] nearest hit of every lane's ray
-    uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kTB);              // [waves][kPairCap]
+    uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kTB);              // [waves][2][kPairCap]
     const uint32_t tid = threadIdx.x, lane = lane_id();
-    uint32_t* pairs = s_pairs + (tid / 64u) * kPairCap;
+    uint32_t* pairs = s_pairs + (tid / 64u) * (2 * kPairCap);                  // (ray lane, row) pairs from the scan
+    uint32_t* fpairs = pairs + kPairCap;                                       // GT > 1: (ray lane, face) pairs that passed their own bound
     unsigned long long* keys = s_key + (tid & ~63u);                           // this wave's 64 records
 
     Path P;
@@ -825,7 +869,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
     bool alive = false;
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
-    unsigned long long casts = 0, mfmas = 0, exact = 0;
+    unsigned long long casts = 0, mfmas = 0, exact = 0, bound_tests = 0;
 #ifdef RT3_PROFILE                                                              // wall-clock ticks (100 MHz) of this wave per phase
     unsigned long long pt_fill = 0, pt_scan = 0, pt_push = 0, pt_test = 0, pt_rest = 0, pt_mark = wall_clock64();
 #define RT3_PHASE(acc) { const unsigned long long now_ = wall_clock64(); acc += now_ - pt_mark; pt_mark = now_; }
@@ -851,10 +895,11 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
 #endif
         if (HAS_SPH && !HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);
         keys[lane] = HAS_SPH ? direct_tests(A, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, [&](uint32_t j) { return A.sph[j]; }) : kKeyNone;
-        uint32_t n_pairs = 0;
+        uint32_t n_pairs = 0, n_fpairs = 0;
 
-        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto&& test) {
+        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto group_tag, auto&& test, auto&& finish) {
             constexpr bool K32 = decltype(k32)::value;                          // spheres: 2 operand fragments (2 KiB) per row block, else 4
+            constexpr uint32_t GROUP = decltype(group_tag)::value;
             constexpr uint32_t kVec = K32 ? 128u : 256u;
             constexpr uint32_t kTile = kTB * kTileLoads / kVec;                 // row blocks per tile (64 KiB at 1024 threads x 4 loads): 32 | 16
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
@@ -870,16 +915,16 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     if constexpr (K32) nz = mfma32k_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane, h0, 3);
                     else nz = mfma16_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
                     RT3_PHASE(pt_scan)
-                    push_pairs16<kTB>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
+                    push_pairs16<kTB, GROUP>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
                     RT3_PHASE(pt_push)
                     mfmas += hb * (K32 ? 8ull : 16ull);
                 }
             }
-            test_all(lane, pairs, n_pairs, test);                               // what is left at the end of the pass
+            finish();                                                           // what is left at the end of the pass
             RT3_PHASE(pt_test)
         };
         if (HAS_TRI) {
-            auto test = [&](uint32_t pair, bool valid) {
+            auto face_test = [&](uint32_t pair, bool valid) {                  // the reference's plane + three-edge test of (ray lane, face) pairs
                 const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
                 const LaneRay r = fetch_ray<REF>(ray, src);
                 exact += (unsigned long long)__popcll(__ballot(valid));
@@ -892,19 +937,82 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                 if (!face_inside(n, p1, p2, p3, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t)) return;
                 if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
             };
-            pass(tri_frags, A.n_tri, std::bool_constant<RT3_FACE_K32 != 0>(), test);
+            if constexpr (GT == 1) {
+                pass(tri_frags, A.n_tri_rows, std::bool_constant<RT3_FACE_K32 != 0>(), std::integral_constant<uint32_t, 1>(), face_test,
+                     [&]() { test_all(lane, pairs, n_pairs, face_test); });
+            } else {
+                // member m of a candidate group: the member's own bounding sphere in f32 — scan_tile's arithmetic with its margin
+                // (rt3_valu_scan.hpp; what k_trace and k_mode_r_fast filter with), on the unit direction the filter saw — then the list of survivors
+                struct FaceMember { float4 b; float ox, oy, oz, dx, dy, dz; uint32_t src, j; bool keep; };
+                auto group_test = group_test_of(
+                    [&](uint32_t pair, bool valid, uint32_t member) {
+                        FaceMember f;
+                        f.src = pair >> kPairLaneShift;
+                        f.j = (pair & ((1u << kPairLaneShift) - 1u)) * GT + member;
+                        const int sl = (int)f.src;
+                        f.ox = __shfl(ray.ox, sl); f.oy = __shfl(ray.oy, sl); f.oz = __shfl(ray.oz, sl);
+                        f.dx = __shfl(ux, sl); f.dy = __shfl(uy, sl); f.dz = __shfl(uz, sl);
+                        bound_tests += (unsigned long long)__popcll(__ballot(valid));
+                        f.keep = valid && f.j < A.n_tri;
+                        f.b = A.tri_bound[f.keep ? f.j : 0u];
+                        return f;
+                    },
+                    [&](const FaceMember& f) {
+                        const float cx = f.b.x - f.ox, cy = f.b.y - f.oy, cz = f.b.z - f.oz;
+                        const float h = fma_(cz, f.dz, fma_(cy, f.dy, cx * f.dx));
+                        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -f.b.w)));
+                        const float disc = fma_(1e-5f, c, fma_(h, h, -c));
+                        const bool keep = f.keep && (__float_as_uint(disc) >> 31) == 0u;      // the sign bit, as scan_tile reads it
+                        const unsigned long long km = __ballot(keep);
+                        if (km == 0ull) return;
+                        if (keep) fpairs[n_fpairs + prefix_count(km)] = (f.src << kPairLaneShift) | f.j;
+                        n_fpairs += (uint32_t)__popcll(km);
+                        __builtin_amdgcn_wave_barrier();
+                        if (n_fpairs >= 64u) {
+                            n_fpairs -= 64u;
+                            face_test(fpairs[n_fpairs + lane], true);
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    });
+                pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, GT>(), group_test,
+                     [&]() { test_all_groups<GT>(lane, pairs, n_pairs, group_test); test_all(lane, fpairs, n_fpairs, face_test); });
+            }
         }
         if (HAS_SPH) {
             if (HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);   // (after the faces' pass: their operands are dead)
-            auto test = [&](uint32_t pair, bool valid) {
-                const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
-                const LaneRay r = fetch_ray<false>(ray, src);
-                exact += (unsigned long long)__popcll(__ballot(valid));
-                if (!valid || j >= A.n_sph) return;
-                float t;
-                if (sphere_root(A.sph[j], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 1u, j));
-            };
-            pass(sph_frags, A.n_sph, std::true_type(), test);
+            if constexpr (GS == 1) {
+                auto test = [&](uint32_t pair, bool valid) {
+                    const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
+                    const LaneRay r = fetch_ray<false>(ray, src);
+                    exact += (unsigned long long)__popcll(__ballot(valid));
+                    if (!valid || j >= A.n_sph) return;
+                    float t;
+                    if (sphere_root(A.sph[j], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 1u, j));
+                };
+                pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, 1>(), test, [&]() { test_all(lane, pairs, n_pairs, test); });
+            } else {
+                // member m of a candidate group: the exact test on the member's record (group order), keyed by the sphere's own index
+                struct SphereMember { float4 s; LaneRay r; uint32_t src, pos; bool ok; };
+                auto group_test = group_test_of(
+                    [&](uint32_t pair, bool valid, uint32_t member) {
+                        SphereMember m;
+                        m.src = pair >> kPairLaneShift;
+                        const uint32_t g = pair & ((1u << kPairLaneShift) - 1u);
+                        m.r = fetch_ray<false>(ray, m.src);
+                        exact += (unsigned long long)__popcll(__ballot(valid));
+                        m.ok = valid && g < A.n_sph_rows;
+                        m.pos = m.ok ? g * GS + member : 0u;
+                        m.s = A.sph_grp[m.pos];
+                        return m;
+                    },
+                    [&](const SphereMember& m) {
+                        float t;
+                        if (m.ok && sphere_root(m.s, m.r.ox, m.r.oy, m.r.oz, m.r.dx, m.r.dy, m.r.dz, A.t_min, t) && t < __builtin_inff())
+                            atomicMin(&keys[m.src], hit_key(t, 1u, A.sph_perm[m.pos]));
+                    });
+                pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, GS>(), group_test,
+                     [&]() { test_all_groups<GS>(lane, pairs, n_pairs, group_test); });
+            }
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t kind, ibest;
@@ -912,7 +1020,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
         key_decode(keys[lane], kind, ibest, tbest);
         shade_lane<HAS_TRI, HAS_SPH, REF>(A, P, alive, kind, ibest, tbest, A.sph, A.sph_invr, A.sph_mat, A.sph_kind);
     }
-    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, mfmas); atomicAdd(A.cast_counter + 2, exact); }
+    if (lane == 0 && casts != 0) { atomicAdd(A.cast_counter, casts); atomicAdd(A.cast_counter + 1, mfmas); atomicAdd(A.cast_counter + 2, exact); atomicAdd(A.cast_counter + 3, bound_tests); }
 #ifdef RT3_PROFILE
     RT3_PHASE(pt_rest)
     if (lane == 0) {

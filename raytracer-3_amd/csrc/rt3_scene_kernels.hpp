@@ -180,4 +180,64 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
     else { mat[i] = make_float4(f.color[0], f.color[1], f.color[2], 0.0f); kind[i] = RT3_MAT_FLAT; }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Group rows of the two-level candidate filter
+// ------------------------------------------------------------------------------------------------------
+// `bounds` holds one sphere (cx, cy, cz, r^2) per primitive — the analytic sphere itself, or the bounding sphere of a face (k_commit_mesh) —
+// in GROUP ORDER: group g = entries [g G, (g + 1) G).  Row g of the matrix filter becomes ONE sphere that encloses the G members, so the
+// scan costs 1 / G of the flat filter's matrix and decode work; a ray that is a candidate for the row then runs the members' own tests.
+// What the row must guarantee is what every filter row guarantees (5.2c): whenever the exact test of ANY member accepts a ray, the row's
+// accumulator has its sign bit clear.
+//   C = mean of the members' centres, R = max (|c_m - C| + r_m): every line that comes within r_m of c_m comes within R of C, and for such
+//   a line the group's discriminant R^2 - dist(C)^2 is at least the member's r_m^2 - dist(c_m)^2 (0 <= dist(c_m) <= r_m).
+//   The exact SPHERE test evaluates its discriminant in f32 and accepts down to a true value of -eta, eta <= 12 u |c_m - o|^2 (u = 2^-24):
+//   the line may miss the member by delta <= min(sqrt(eta), eta / 2 r_m), which costs the group's discriminant up to 2 (R + delta) delta
+//     <= 1.7e-3 R |o'| + 1.7e-3 R rho + 2.9e-6 (|o'|^2 + rho^2),      rho = |C'| + R  (primes: about the filter's centre)
+//     <= [0.034 R^2 + 1.7e-3 R rho + 2.9e-6 rho^2]  +  2.4e-5 |o'|^2    (R |o'| <= (40 R^2 + |o'|^2 / 40) / 2).
+//   The ray-side part is a third of what the K = 32 margin leaves free (0.35 eps32 |o'|^2 = 7.7e-5 |o'|^2, 5.2c); the bracket is added to
+//   the row's radius here, rounded up: R_eff^2 = 1.04 R^2 + 2e-3 R rho + 4e-6 rho^2.  (The exact FACE test never accepts a line that misses
+//   the face's bound — its inflation is 80x the rounding of a hit point — so for faces the same inflation is pure slack.)
+// A member with r^2 >= 3e38 (a face without a bounded hit region) makes its row an always-candidate; members with a negative or non-finite
+// record (padding; spheres no exact test can ever accept) do not count; a row without members can never be a candidate.
+__global__ void k_group_frags(const float4* __restrict__ bounds, uint32_t n_entries, uint32_t group, uint32_t n_rows_padded,
+                              const uint32_t* __restrict__ box, float ecx, float ecy, float ecz, u32x4* __restrict__ frag) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_rows_padded) return;
+    float centre[3] = { ecx, ecy, ecz };
+    if (box) box_centre(box, centre);
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    uint32_t members = 0;
+    bool always = false;
+    for (uint32_t m = 0; m < group; m++) {
+        const uint64_t j = (uint64_t)g * group + m;
+        if (j >= n_entries) break;
+        const float4 b = bounds[j];
+        if (!(b.w >= 0.0f) || !(b.x - b.x == 0.0f) || !(b.y - b.y == 0.0f) || !(b.z - b.z == 0.0f)) continue;
+        if (!(b.w < 3e38f)) { always = true; continue; }
+        sx += b.x; sy += b.y; sz += b.z; members++;
+    }
+    float fx = 0.0f, fy = 0.0f, fz = 0.0f, kj = kNeverCandidate;
+    if (always) kj = kAlwaysCandidate;
+    else if (members != 0) {
+        const double cx = sx / members, cy = sy / members, cz = sz / members;
+        double R = 0.0;
+        for (uint32_t m = 0; m < group; m++) {
+            const uint64_t j = (uint64_t)g * group + m;
+            if (j >= n_entries) break;
+            const float4 b = bounds[j];
+            if (!(b.w >= 0.0f) || !(b.x - b.x == 0.0f) || !(b.y - b.y == 0.0f) || !(b.z - b.z == 0.0f) || !(b.w < 3e38f)) continue;
+            const double ddx = b.x - cx, ddy = b.y - cy, ddz = b.z - cz;
+            R = fmax(R, sqrt(ddx * ddx + ddy * ddy + ddz * ddz) + sqrt((double)b.w));
+        }
+        fx = (float)(cx - (double)centre[0]); fy = (float)(cy - (double)centre[1]); fz = (float)(cz - (double)centre[2]);
+        const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz, rho = sqrt(c2) + R;
+        const double r2 = (1.04 * R * R + 2e-3 * R * rho + 4e-6 * rho * rho) * (1.0 + 1e-6) + 1e-30;
+        kj = r2 < 1e30 ? filter_kj32(c2, r2) : kAlwaysCandidate;
+    }
+    uint32_t fr[4][4];
+    bound_frag32_row(fx, fy, fz, kj, fr);
+    for (uint32_t q = 0; q < 4; q++) frag[frag32_index(g / 32, g % 32, q)] = u32x4{ fr[q][0], fr[q][1], fr[q][2], fr[q][3] };
+}
+
 }  // namespace

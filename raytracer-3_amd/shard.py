@@ -21,8 +21,11 @@ import torch.distributed as dist
 class FrameGatherer:
     """Owns the tile buffer of this rank and, on rank 0, the receive buffer and the assembled frame."""
 
-    def __init__(self, rt3, params_list, rank, device, force_collective=False, renderer=None):
+    def __init__(self, rt3, params_list, rank, device, force_collective=False, renderer=None, stage_host=False):
         self.force_collective = force_collective           # run the gather even with one rank (rehearsal of the RCCL path)
+        # stage_host: the tile is rendered on `device` but travels through host memory and a CPU backend (gloo) — the rehearsal of the
+        # multi-rank control flow with several ranks on ONE GPU (RCCL refuses two ranks on one device); never the measured path
+        self.stage_host = stage_host
         self.world = len(params_list)
         self.rank = rank
         self.params = params_list[rank]
@@ -34,6 +37,9 @@ class FrameGatherer:
         max_rows = max(self.rows)
         # every rank sends the same number of rows (padded): gather needs equal shapes
         self.tile = torch.zeros((max_rows, self.width), dtype=torch.int32, device=device)
+        self.host_tile = torch.zeros((max_rows, self.width), dtype=torch.int32) if stage_host else None
+        if stage_host:
+            device = torch.device("cpu")                   # receive buffer, row maps and the assembled frame live where the backend works
         self.frame = None
         self.recv = None
         self.gather_list = None
@@ -55,7 +61,9 @@ class FrameGatherer:
     def gather(self, stream_ptr=None):
         """Collects every rank's tile on rank 0 and returns the assembled frame there (None elsewhere)."""
         if self.world > 1 or self.force_collective:
-            dist.gather(self.tile, self.gather_list, dst=0)
+            if self.stage_host:
+                self.host_tile.copy_(self.tile)            # (synchronises with the render on the current stream)
+            dist.gather(self.host_tile if self.stage_host else self.tile, self.gather_list, dst=0)
             if self.rank == 0:
                 rows = self.recv.view(-1, self.width)
                 self.frame.index_copy_(0, self.dst_rows, rows if self.src_rows is None else rows.index_select(0, self.src_rows))

@@ -31,7 +31,7 @@ def test_wire_struct_layouts(rt3):
     assert rt3.MATERIAL.itemsize == 20
     assert C.sizeof(rt3.rt3_camera) == 48           # 4 x vec3 (Camera.hpp:27-34)
     assert C.sizeof(rt3.rt3_params) == 44
-    assert C.sizeof(rt3.rt3_stats) == 64
+    assert C.sizeof(rt3.rt3_stats) == 80 and rt3.ABI_VERSION == 3          # include/rt3.h: RT3_ABI_VERSION 3 (round 3: + filter_tests, bound_tests)
 
 
 def test_no_cpu_fallback_without_gpu(rt3):

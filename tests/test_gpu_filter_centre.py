@@ -58,4 +58,6 @@ def test_spheres_far_from_the_origin_stay_filtered(rt3, renderer, n):
         cam = rt3.Camera().look_at(64, 48, (dx, dy + 1.0, dz + 2.0), (dx, dy, dz - 8.0), (0.0, 1.0, 0.0), 50.0, 1.0)
         case = dict(cam=cam.c, spheres=cr, smats=mats, params=dict(width=64, height=48, spp=4, max_depth=8, seed=5, flags=1, t_min=0.001))
         per_cast.append(render_both(renderer, case))
-    assert 0 < per_cast[0] < 40 and per_cast[1] < 3 * per_cast[0] + 5, per_cast
+    # n = 2000 runs the two-level filter: a candidate GROUP brings its 8 members to the exact test (84 per ray cast, of 2000); what this test
+    # is about is that the count does not grow when the scene moves away from the world origin
+    assert 0 < per_cast[0] < (40 if n <= 512 else 160) and per_cast[1] < 3 * per_cast[0] + 5, per_cast

@@ -1,0 +1,109 @@
+"""The two-level candidate filter of k_trace_mfma_tiled: a row of the matrix filter is the bounding sphere of a GROUP of
+primitives (faces in face order, spheres in the order of a spatial median split), a candidate row expands into member tests.  It only has to be
+conservative — the exact tests and the (t, kind, index) key are those of the flat filter — so every frame must equal the flat filter's, the
+unfiltered kernel's and the oracle's bit for bit, while the matrix filter evaluates 1 / GROUP of the (ray, row) pairs."""
+import numpy as np
+import pytest
+
+from cases import hip_render, mode_x_cases, oracle_render
+from test_gpu_brute import random_soup
+
+pytestmark = pytest.mark.gpu
+
+
+def three_ways(renderer, case):
+    """(grouped, flat, brute) frames and the stats of the first two."""
+    grouped = hip_render(renderer, case)
+    st_g = renderer.stats()
+    renderer.force_flat_filter(True)
+    try:
+        flat = hip_render(renderer, case, upload=False)
+        st_f = renderer.stats()
+    finally:
+        renderer.force_flat_filter(False)
+    renderer.force_brute(True)
+    try:
+        brute = hip_render(renderer, case, upload=False)
+    finally:
+        renderer.force_brute(False)
+    return grouped, flat, brute, st_g, st_f
+
+
+@pytest.mark.parametrize("seed,n_faces,n_sph,scale", [(11, 700, 0, 1.0), (12, 0, 900, 1.0), (13, 1301, 707, 1.0), (14, 605, 515, 1e3),
+                                                      (15, 41, 530, 1e-2), (16, 9, 513, 1.0), (17, 2049, 0, 1.0)])
+def test_grouped_filter_equals_flat_filter_equals_brute_on_random_soups(rt3, renderer, seed, n_faces, n_sph, scale):
+    """Random triangle soups (skewed stored normals, degenerate faces: always-candidate members) and random spheres, ragged group counts,
+    three coordinate scales.  Random order is the WORST case for the groups' bounds (face groups span the scene): still the same pixels."""
+    rng = np.random.default_rng(seed)
+    faces, verts, fm, cr, sm = random_soup(rng, n_faces, n_sph, scale, rt3)
+    cam = rt3.Camera().update(96, 64, 1.0, 3.0, 2.0)
+    case = dict(cam=cam.c, params=dict(width=96, height=64, spp=4, max_depth=6, seed=seed, flags=1, t_min=0.001 * scale))
+    if n_faces:
+        case.update(faces=faces, verts=verts, fmats=fm)
+    if n_sph:
+        case.update(spheres=cr, smats=sm)
+    grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
+    assert np.array_equal(flat, brute), "flat filter != brute"
+    assert np.array_equal(grouped, brute), "two-level filter != brute: %d pixels" % int((grouped != brute).sum())
+    assert st_g.ray_casts == st_f.ray_casts
+    assert st_f.filter_tests == st_f.prim_tests                           # flat: one row per primitive
+    rows_g, rows_f = st_g.filter_tests // st_g.ray_casts, st_f.filter_tests // st_f.ray_casts
+    assert rows_g <= rows_f // 8 + 2 and st_g.mfma_instructions < st_f.mfma_instructions
+    if n_faces:
+        assert st_g.bound_tests > 0 and st_f.bound_tests == 0
+    want, casts = oracle_render(case, threads=16)
+    assert np.array_equal(grouped, want) and casts == st_g.ray_casts
+
+
+def test_coherent_scenes_test_fewer_members_than_the_flat_filter_tests_rows(rt3, renderer):
+    """Where the order is coherent (a tessellated mesh; spheres after the median split) the groups are tight: the Cornell-style box of config 5
+    (small version) and the 100k-sphere scene of config 4 (small version) run far fewer filter tests and about as many exact tests."""
+    f, v, m = rt3.scene_cornell(16)
+    cam = rt3.Camera().update(128, 128, 2.0, 2.0, 2.0)
+    case = dict(faces=f, verts=v, fmats=m, cam=cam.c, params=dict(width=128, height=128, spp=4, max_depth=8, seed=4, flags=1 | 2))
+    grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
+    assert np.array_equal(grouped, flat) and np.array_equal(flat, brute)
+    assert st_g.filter_tests * 7 < st_f.filter_tests
+    assert st_g.exact_tests < 2 * st_f.exact_tests and st_g.bound_tests < st_f.filter_tests // 4
+    cr, mats = rt3.scene_stress(6000, 7)
+    cam = rt3.Camera().look_at(160, 90, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
+    case = dict(spheres=cr, smats=mats, cam=cam.c, params=dict(width=160, height=90, spp=4, max_depth=8, seed=2, flags=1))
+    grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
+    assert np.array_equal(grouped, flat) and np.array_equal(flat, brute)
+    assert st_g.filter_tests * 7 < st_f.filter_tests and st_g.exact_tests < st_f.filter_tests // 8
+
+
+def test_spheres_no_exact_test_can_accept_and_direct_spheres_stay_out_of_the_groups(rt3, renderer):
+    """Non-finite sphere records (never hit by the exact test, and a NaN centre would poison a group's bound) and the spheres on the direct
+    list (a ground sphere: tested for every ray, member of no group) around 600 ordinary spheres."""
+    rng = np.random.default_rng(5)
+    n = 600
+    cr = np.zeros((n, 4), np.float32)
+    cr[:, :3] = rng.uniform(-1.0, 1.0, (n, 3)) * np.float32([6.0, 0.5, 6.0]) + np.float32([0.0, 0.3, -8.0])
+    cr[:, 3] = rng.uniform(0.05, 0.3, n)
+    cr[0] = (0.0, -1000.0, -8.0, 1000.0)                                  # the ground: direct
+    cr[17, 0] = np.nan
+    cr[99, 1] = np.inf
+    cr[300, 3] = np.float32(3e38)                                         # r^2 overflows
+    mats = np.zeros(n, rt3.MATERIAL)
+    mats["kind"] = rng.integers(1, 4, n)
+    mats["rgb"] = rng.uniform(0.3, 1.0, (n, 3))
+    mats["param"] = np.where(mats["kind"] == 3, 1.5, 0.1).astype(np.float32)
+    cam = rt3.Camera().look_at(120, 68, (0.0, 2.0, 2.0), (0.0, 0.3, -8.0), (0.0, 1.0, 0.0), 50.0, 1.0)
+    case = dict(spheres=cr, smats=mats, cam=cam.c, params=dict(width=120, height=68, spp=4, max_depth=10, seed=8, flags=1))
+    grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
+    assert np.array_equal(flat, brute) and np.array_equal(grouped, brute)
+    want, casts = oracle_render(case, threads=16)
+    assert np.array_equal(grouped, want) and casts == st_g.ray_casts
+
+
+@pytest.mark.parametrize("name", sorted(mode_x_cases().keys()))
+def test_environment_switch_selects_the_flat_filter(renderer, name, monkeypatch):
+    case = mode_x_cases()[name]
+    want = hip_render(renderer, case)
+    st = renderer.stats()
+    monkeypatch.setenv("RT3_NO_GROUPS", "1")
+    assert np.array_equal(hip_render(renderer, case, upload=False), want)
+    st_f = renderer.stats()
+    if case.get("faces") is not None:                                     # (the sphere cases of this set run k_trace_mfma32: no rows to group)
+        assert st_f.filter_tests == st_f.prim_tests and st.filter_tests < st_f.filter_tests

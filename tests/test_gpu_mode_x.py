@@ -149,6 +149,61 @@ def test_config4_depth_50_rows_against_the_oracle(rt3, renderer):
     assert_same(np.stack([whole[200], whole[740]]), want, "config 4 depth 50, whole frame")
 
 
+def _golden_rows(name):
+    import json
+    import os
+    import zlib
+    from cases import GOLDEN
+    meta = json.load(open(os.path.join(GOLDEN, "config45_rows.json")))[name]
+    rows = np.load(os.path.join(GOLDEN, "config45_rows.npz"))[name]
+    assert [int(zlib.crc32(np.ascontiguousarray(r, "<u4").tobytes())) for r in rows] == meta["row_crc32"]      # the fixture is intact
+    return meta, rows
+
+
+def test_config4_full_spp_rows_equal_the_oracle_rows(rt3, renderer):
+    """BASELINE.json configs[3] at its OWN sample budget: 100 000 spheres, 1920x1080, 256 spp, depth 50.  Two full-width rows (270 and 810)
+    against the oracle's, which were rendered once in the build container (tests/golden/make_config45_golden.py, 450 s on 6 cores) and are
+    committed with their CRCs and ray-cast count: every sample index 0 .. 255 of these pixels goes through the tiled matrix-filter kernel."""
+    meta, want = _golden_rows("config4")
+    cr, mats = rt3.scene_stress(100000, 43)
+    W, H = 1920, 1080
+    cam = rt3.Camera().look_at(W, H, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
+    assert meta["params"] == dict(width=W, height=H, spp=256, max_depth=50, seed=9, flags=1)
+    case = dict(spheres=cr, smats=mats, cam=cam.c, params=meta["params"])
+    got = hip_render(renderer, case, **meta["shard"])
+    assert_same(got, want, "config 4, 256 spp, rows %s" % meta["frame_rows"])
+    assert renderer.stats().ray_casts == meta["ray_casts"]
+
+
+def test_config4_full_frame_at_256_spp_is_the_union_of_its_eight_shards(rt3, renderer):
+    """The complete config-4 frame at 256 spp, depth 50 (5.3e8 samples, 2.5e9 ray casts over 100 000 spheres): the whole frame equals the
+    union of the eight single-row-interleaved shards an 8-GPU run renders, and contains the two oracle rows."""
+    meta, want = _golden_rows("config4")
+    cr, mats = rt3.scene_stress(100000, 43)
+    W, H = 1920, 1080
+    cam = rt3.Camera().look_at(W, H, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
+    case = dict(spheres=cr, smats=mats, cam=cam.c, params=meta["params"])
+    whole = hip_render(renderer, case)
+    assert renderer.stats().samples == W * H * 256
+    assert_same(np.stack([whole[r] for r in meta["frame_rows"]]), want, "config 4, 256 spp, whole frame")
+    plist = [rt3.make_params(**dict(meta["params"], tile_rows=1, tile_index=i, tile_count=8)) for i in range(8)]
+    tiles = [hip_render(renderer, case, upload=False, tile_rows=1, tile_index=i, tile_count=8) for i in range(8)]
+    assert_same(rt3.deinterleave(tiles, plist, H, W), whole, "config 4, 256 spp: union of the 8 shards")
+
+
+def test_config5_full_spp_rows_equal_the_oracle_rows(rt3, renderer):
+    """BASELINE.json configs[4] at its OWN sample budget: the Cornell-style box (47 106 triangles, emissive quad), 1024x1024, 2048 spp,
+    depth 50, black background.  Rows 300 and 812 against the oracle's (make_config45_golden.py: about 80 minutes on 6 cores)."""
+    meta, want = _golden_rows("config5")
+    faces, verts, fmats = rt3.scene_cornell(64)
+    cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
+    assert meta["params"] == dict(width=1024, height=1024, spp=2048, max_depth=50, seed=6, flags=3)
+    case = dict(faces=faces, verts=verts, fmats=fmats, cam=cam.c, params=meta["params"])
+    got = hip_render(renderer, case, **meta["shard"])
+    assert_same(got, want, "config 5, 2048 spp, rows %s" % meta["frame_rows"])
+    assert renderer.stats().ray_casts == meta["ray_casts"]
+
+
 def test_stress_scene_small_whole_image(rt3, renderer):
     cr, mats = rt3.scene_stress(3000, 7)                                     # 3 LDS tiles, last one ragged
     cam = rt3.Camera().look_at(160, 90, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)

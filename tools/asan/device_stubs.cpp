@@ -35,6 +35,7 @@ int rt3_device_read_words(rt3_ctx*, const void*, uint64_t, uint32_t*) { return R
 int rt3_get_stats(rt3_ctx*, rt3_stats*) { return RT3_E_DEVICE; }
 int rt3_debug_force_plain_mode_r(rt3_ctx*, int) { return RT3_E_DEVICE; }
 int rt3_debug_force_brute(rt3_ctx*, int) { return RT3_E_DEVICE; }
+int rt3_debug_force_flat_filter(rt3_ctx*, int) { return RT3_E_DEVICE; }
 int rt3_debug_arith(rt3_ctx*, const float*, const float*, uint32_t, float*, float*, float*, float*, float*, float*, uint32_t*) { return RT3_E_DEVICE; }
 // (rt3_rows_owned / rt3_row_of_local are pure host arithmetic that happens to live in rt3_device.hip)
 uint32_t rt3_rows_owned(const rt3_params* p) {

@@ -31,5 +31,6 @@ else:
     p = rt3.make_params(1024, 1024, spp=spp, max_depth=50, flags=3)
 r.render_path(cam.c, p)
 st = r.stats()
-print("config %s spp %d: trace %.3f ms, %d casts, %d mfma, %.2f exact tests per cast" % (which, spp, st.trace_ms, st.ray_casts, st.mfma_instructions,
-                                                                                       st.exact_tests / max(1, st.ray_casts)))
+print("config %s spp %d: trace %.3f ms, %d casts, %d mfma, %.2f exact tests per cast, %.1f bound tests per cast, %d filter rows per cast, %.3e prim tests/s"
+      % (which, spp, st.trace_ms, st.ray_casts, st.mfma_instructions, st.exact_tests / max(1, st.ray_casts), st.bound_tests / max(1, st.ray_casts),
+         st.filter_tests // max(1, st.ray_casts), st.prim_tests / (st.trace_ms * 1e-3)))
