@@ -62,6 +62,7 @@ struct rt3_ctx {
     // group rows of the two-level filter: faces in face order, spheres in the order of a spatial median split
     u32x4* d_tri_gfrag = nullptr; uint32_t n_tri_groups = 0;
     u32x4* d_sph_gfrag = nullptr; float4* d_sph_grp = nullptr; uint32_t* d_sph_perm = nullptr; uint32_t n_sph_groups = 0;
+    uint32_t* d_strips = nullptr; size_t strip_entries = 0;          // deferred member tests: kStripPairs pairs per wave of the grid
 
     // work buffers
     Rgb* d_rad = nullptr; size_t rad_entries = 0;
@@ -412,7 +413,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r,
-                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm };
+                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -532,13 +533,13 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
                        ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
                        (u32x4*)ctx->d_tri_frag_r, n_frag_rows, (const uint32_t*)ctx->d_box, 0.5f);
     RT3_HIP(hipGetLastError());
-    // rows of the two-level filter: the bounding sphere of every kGroup consecutive faces, from the faces' own bounds (meshes come in a
+    // rows of the two-level filter: the bounding sphere of every kGroupTri consecutive faces, from the faces' own bounds (meshes come in a
     // coherent order: a tessellation emits neighbours one after the other)
-    ctx->n_tri_groups = (n + kGroup - 1u) / kGroup;
+    ctx->n_tri_groups = (n + kGroupTri - 1u) / kGroupTri;
     {
         const uint32_t n_group_rows = (ctx->n_tri_groups + 31u) / 32u * 32u;
         RT3_HIP(hipMalloc((void**)&ctx->d_tri_gfrag, (size_t)n_group_rows * 4 * sizeof(u32x4)));
-        hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_bound, n, kGroup,
+        hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_bound, n, kGroupTri,
                            n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_gfrag);
         RT3_HIP(hipGetLastError());
     }
@@ -595,19 +596,19 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
     if ((rc = upload(ctx, &ctx->d_sph, sph)) || (rc = upload(ctx, &ctx->d_sph_invr, invr)) ||
         (rc = upload(ctx, &ctx->d_sph_mat, mat)) || (rc = upload(ctx, &ctx->d_sph_kind, kind)))
         return rc;
-    // rows of the two-level filter: groups of kGroup spheres in the order of a spatial median split
+    // rows of the two-level filter: groups of kGroupSph spheres in the order of a spatial median split
     {
-        const std::vector<uint32_t> order = sphere_group_order(center_radius, n, ctx->direct, ctx->n_direct, kGroup);
+        const std::vector<uint32_t> order = sphere_group_order(center_radius, n, ctx->direct, ctx->n_direct, kGroupSph);
         std::vector<float4> grp(order.size(), kPadSphere);
         for (size_t k = 0; k < order.size(); k++) if (order[k] != 0xFFFFFFFFu) grp[k] = sph[order[k]];
         if ((rc = upload(ctx, &ctx->d_sph_grp, grp)) || (rc = upload(ctx, &ctx->d_sph_perm, order))) return rc;
         if (ctx->d_sph_gfrag) { RT3_HIP(hipFree(ctx->d_sph_gfrag)); ctx->d_sph_gfrag = nullptr; }
-        ctx->n_sph_groups = (uint32_t)(order.size() / kGroup);
+        ctx->n_sph_groups = (uint32_t)(order.size() / kGroupSph);
         if (ctx->n_sph_groups) {
             const uint32_t n_group_rows = (ctx->n_sph_groups + 31u) / 32u * 32u;
             RT3_HIP(hipMalloc((void**)&ctx->d_sph_gfrag, (size_t)n_group_rows * 4 * sizeof(u32x4)));
             hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_sph_grp,
-                               (uint32_t)order.size(), kGroup, n_group_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2],
+                               (uint32_t)order.size(), kGroupSph, n_group_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2],
                                ctx->d_sph_gfrag);
             RT3_HIP(hipGetLastError());
             RT3_HIP(hipStreamSynchronize(ctx->stream));             // a render may come on another stream
@@ -813,7 +814,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     const bool mfma_single = use_mfma && !has_tri && has_sph && ctx->n_sph <= kMfmaSphMax && !getenv("RT3_FORCE_TILED");   // (A/B knob)
     const bool single_k64 = mfma_single && getenv("RT3_MFMA_K64") != nullptr;
     const bool sph_lds = has_sph && ctx->n_sph <= kSphLdsMax;
-    const bool grouped = kGroup > 1 && !ctx->force_flat && !getenv("RT3_NO_GROUPS");
+    const bool grouped = kGroupTri > 1 && kGroupSph > 1 && !ctx->force_flat && !getenv("RT3_NO_GROUPS");
     A.n_tri_rows = grouped ? ctx->n_tri_groups : ctx->n_faces;
     A.n_sph_rows = grouped ? ctx->n_sph_groups : ctx->n_sph;
     A.sph_grp = ctx->d_sph_grp; A.sph_perm = ctx->d_sph_perm;
@@ -833,11 +834,11 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         block = kMB;
         kptr = single_k64 ? (const void*)k_trace_mfma : (const void*)k_trace_mfma32;
     } else if (use_mfma) {
-        // the two-level filter (rows = groups of kGroup primitives) unless RT3_NO_GROUPS=1 asks for the flat one (A/B reference, tests)
-        constexpr uint32_t G = kGroup;
+        // the two-level filter (rows = groups of primitives) unless RT3_NO_GROUPS=1 asks for the flat one (A/B reference, tests)
+        constexpr uint32_t GT = kGroupTri, GS = kGroupSph;
         if (grouped)
-            tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false, G, G> : (ref ? k_trace_mfma_tiled<true, false, true, G, 1> : k_trace_mfma_tiled<true, false, false, G, 1>))
-                            : k_trace_mfma_tiled<false, true, false, 1, G>;
+            tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false, GT, GS> : (ref ? k_trace_mfma_tiled<true, false, true, GT, 1> : k_trace_mfma_tiled<true, false, false, GT, 1>))
+                            : k_trace_mfma_tiled<false, true, false, 1, GS>;
         else
             tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
                             : k_trace_mfma_tiled<false, true, false>;
@@ -855,6 +856,10 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     if ((rc = blocks_per_cu(ctx, kptr, block, lds, &per_cu))) return rc;
     if (per_cu < 1) return fail(ctx, RT3_E_DEVICE, "the trace kernel does not fit on a CU");
     per_cu = std::min(per_cu, 8);
+    if (tiled && grouped) {                                         // one strip per wave of the largest grid this launch configuration can have
+        if ((rc = ensure(ctx, &ctx->d_strips, &ctx->strip_entries, (size_t)ctx->num_cu * per_cu * (kTB / 64u) * kStripPairs))) return rc;
+        A.pair_strips = ctx->d_strips;
+    }
 
     RT3_HIP(hipEventRecord(ctx->ev_begin, stream));
     RT3_HIP(hipMemsetAsync(ctx->d_casts, 0, 128, stream));

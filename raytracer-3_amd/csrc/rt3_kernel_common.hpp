@@ -135,6 +135,7 @@ struct TraceArgs {
     // (rt3_set_spheres): sph_grp holds their (cx, cy, cz, r^2) records in GROUP order, sph_perm the sphere index of each (0xFFFFFFFF: padding,
     // and the direct spheres, which are not in any group).  *_rows: rows the pass scans (= primitives when G is 1).
     const float4* sph_grp; const uint32_t* sph_perm; uint32_t n_sph_rows, n_tri_rows;
+    uint32_t* pair_strips;   // [wave of the grid][kStripPairs]: candidate (ray lane, row) pairs set aside for the end of a pass (deferred member tests)
     uint32_t* work_counter;
     unsigned long long* cast_counter;
 };

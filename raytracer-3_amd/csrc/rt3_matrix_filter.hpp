@@ -96,9 +96,15 @@ struct RayOperands { u32x4 b[2][3]; };
 // rule for this opcode): that build fails tests/test_gpu_repeatability.py, while every build in which one instruction or one wait
 // state separates the two passes.  So the conversion is issued through inline asm with ONE trailing wait state (round 1 used 2 + 4).
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+#ifdef RT3_PK_BF16_COMPILER                                         // the build that FAILS tests/test_gpu_repeatability.py: hipcc's own conversion (experiments only:
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));       // tools/cvt_isa_check.py compares its ISA with the product's)
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){ lo, hi }, bf16x2_));
+#else
     uint32_t r;
     asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
+#endif
 }
 // v_permlane32_swap(x, y): x's upper half-wave <-> y's lower half-wave; set0 = new x, set1 = new y
 __device__ __forceinline__ void swap32(uint32_t x, uint32_t y, uint32_t& set0, uint32_t& set1) {
@@ -548,12 +554,9 @@ __device__ __forceinline__ void test_all(uint32_t lane, const uint32_t* pairs, u
 // Pushes this lane's candidates of the tile just scanned (rows row0 ..) into the wave's list and tests 64 pairs whenever that many are
 // there; n_pairs (wave-uniform) carries the remainder to the next tile.  The words are mfma16_scan_tile's: bit 8 G + 4 h + j of word blk
 // is (ray lane 16 G + c, row 32 blk + 16 h + 4 g + j), with (g, c) the pushing lane's own position.
-// GROUP > 1 (two-level filter): a row is a group of GROUP primitives and a pair expands into GROUP member tests, so a round
-// of the 64 lanes takes 64 / GROUP pairs — lane k tests member k % GROUP of pair k / GROUP — and `test` gets the member beside the pair.
-template <uint32_t STRIDE = kMB, uint32_t GROUP = 1, class Test>
+template <uint32_t STRIDE = kMB, class Test>
 __device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
                                              uint32_t& n_pairs, Test&& test) {
-    constexpr uint32_t PER = 64u / GROUP;                           // pairs per round
     CandIter it = { nz, 0u, 0u, n_blocks };
     const uint32_t c = lane & 15u, g4 = (lane >> 4) * 4u;
     for (;;) {
@@ -566,44 +569,57 @@ __device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, con
         if (have) pairs[n_pairs + prefix_count(m)] = (ray_lane << kPairLaneShift) | row;
         n_pairs += (uint32_t)__popcll(m);
         __builtin_amdgcn_wave_barrier();
-        if constexpr (GROUP == 1) {
-            if (n_pairs >= 64u) {
-                n_pairs -= 64u;
-                test(pairs[n_pairs + lane], true);
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else if (n_pairs >= PER) {
-            // rounds of member tests, software-pipelined: the gathers of the next round (member records from L2, the rays from their lanes) are
-            // in flight while this round computes — a round alone is all latency
-            n_pairs -= PER;
-            auto cur = test.fetch(pairs[n_pairs + lane / GROUP], true, lane % GROUP);
-            while (n_pairs >= PER) {
-                n_pairs -= PER;
-                auto nxt = test.fetch(pairs[n_pairs + lane / GROUP], true, lane % GROUP);
-                test.compute(cur);
-                __builtin_amdgcn_wave_barrier();
-                cur = nxt;
-            }
-            test.compute(cur);
+        if (n_pairs >= 64u) {
+            n_pairs -= 64u;
+            test(pairs[n_pairs + lane], true);
             __builtin_amdgcn_wave_barrier();
         }
     }
 }
-// The rest of a group-pair list (fewer than 64 / GROUP pairs) at the end of a pass.
-template <uint32_t GROUP, class Test>
-__device__ __forceinline__ void test_all_groups(uint32_t lane, const uint32_t* pairs, uint32_t& n_pairs, Test&& test) {
-    constexpr uint32_t PER = 64u / GROUP;
-    while (n_pairs != 0u) {
-        const uint32_t take = n_pairs < PER ? n_pairs : PER;
-        n_pairs -= take;
-        const bool valid = lane / GROUP < take;
-        test.compute(test.fetch(valid ? pairs[n_pairs + lane / GROUP] : 0u, valid, lane % GROUP));
-        __builtin_amdgcn_wave_barrier();
+
+// Two-level filter: a row of the scan is a GROUP of primitives, a candidate (ray lane, group row) pair expands into the members'
+// tests.  The pairs of a pass are not tested between two tile barriers — there the 16 waves of the workgroup would wait for whichever has the most
+// candidates in THIS tile, and a batch of member tests is mostly latency — but set aside, 64 at a time (one coalesced 256-byte store), in the
+// wave's own strip of global memory and tested when the pass has seen every tile: one run of full 64-lane batches with no barrier in it
+// (wave time at the tile barriers on the 100 000-sphere scene: 43 % -> 13 %).  In a batch every LANE owns one pair: it fetches the ray of the
+// owning lane once (ds_bpermute) and walks the group's members itself — their records are the lane's own 128 contiguous bytes — so the
+// per-pair overhead is paid once per GROUP member tests.  A strip holds kStripPairs pairs; a wave that fills it drains it on the spot.
+constexpr uint32_t kStripPairs = 8192;                              // per wave: 32 KiB (x 16 waves x 256 workgroups = 128 MiB)
+template <uint32_t STRIDE = kMB, class Spill>
+__device__ __forceinline__ void push_pairs16_spill(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
+                                                   uint32_t& n_pairs, Spill&& spill) {
+    push_pairs16<STRIDE>(nz, n_blocks, bm, row0, lane, pairs, n_pairs, [&](uint32_t v, bool) { spill(v); });
+}
+// Runs `group(pair, valid, part)` — ALL lanes call it — on the n_strip pairs of the wave's strip.  LPP lanes share a pair: lane k of a batch takes
+// pair k / LPP and the members [part, part + 1) * GROUP / LPP of its group, part = k % LPP.  What LPP trades (100 000-sphere scene, per pair):
+//   1 lane  per pair: the ray is fetched once per 8 member tests (3 wave-instructions per pair), but every load instruction touches 64 different
+//                     cache lines (8 tag look-ups per pair): the texture path, not the ALU, sets the pace (measured: no faster than 8 lanes)
+//   8 lanes per pair: one look-up per pair (the 8 lanes read one 128-byte line), 8 wave-instructions per pair: the vector ALU sets the pace
+//   2 / 4 lanes per pair: 4 / 2 look-ups and 3.2 / 3.7 wave-instructions per pair
+// Measured in one process (profiles/r03_ab_lanes_per_pair.log), 100 000 spheres | 47 106 faces: 1 lane 46.6 | 21.7 ms, 2 lanes 44.5 | 19.3 (the default,
+// RT3_LANES_PER_PAIR), 4 lanes 46.7 | 20.1, 8 lanes 53.9 | 21.0.
+#ifndef RT3_LANES_PER_PAIR
+#define RT3_LANES_PER_PAIR 2
+#endif
+constexpr uint32_t kLanesPerPair = RT3_LANES_PER_PAIR;
+template <uint32_t LPP, class GroupFn>
+__device__ __forceinline__ void drain_strip(uint32_t lane, const uint32_t* strip, uint32_t n_strip, GroupFn&& group) {
+    constexpr uint32_t PER = 64u / LPP;                             // pairs per batch
+    if (n_strip == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");          // the strip was written by other lanes of this wave
+    uint32_t next = strip[min(lane, n_strip - 1u)];
+    for (uint32_t base = 0; base < n_strip; base += 64u) {
+        const uint32_t chunk = next;
+        if (base + 64u < n_strip) next = strip[min(base + 64u + lane, n_strip - 1u)];      // in flight during this chunk's batches
+#pragma unroll
+        for (uint32_t k0 = 0; k0 < 64u; k0 += PER) {
+            if (base + k0 >= n_strip) break;                        // (wave-uniform)
+            const uint32_t k = k0 + lane / LPP;
+            group(LPP == 1 ? chunk : (uint32_t)__shfl((int)chunk, (int)k), base + k < n_strip, lane % LPP);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
-// A member test in two halves, so that the loads of one round can be issued before the arithmetic of the previous one.
-template <class Fetch, class Compute> struct GroupTest { Fetch fetch; Compute compute; };
-template <class Fetch, class Compute> __device__ __forceinline__ GroupTest<Fetch, Compute> group_test_of(Fetch f, Compute c) { return GroupTest<Fetch, Compute>{ f, c }; }
 
 // Sphere scenes of <= 512 spheres: everything the loop touches lives in LDS, waves never synchronise after the prologue.
 __global__ __launch_bounds__(kMB) void k_trace_mfma(const TraceArgs A, const u32x4* __restrict__ frags, uint32_t n_blocks) {
@@ -846,10 +862,13 @@ __device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict
 // a row is the bounding sphere of G primitives, a candidate row expands into G member tests: for spheres the exact test itself, for faces
 // first the f32 test of the member's own bounding sphere (the vector-ALU kernels' scan arithmetic, 16-byte record) whose survivors are
 // compacted into a second pair list and get the reference's plane + three-edge test, 64 at a time).  Both must divide 64.
-#ifndef RT3_GROUP
-#define RT3_GROUP 8
+#ifndef RT3_GROUP_TRI
+#define RT3_GROUP_TRI 8
 #endif
-constexpr uint32_t kGroup = RT3_GROUP;
+#ifndef RT3_GROUP_SPH
+#define RT3_GROUP_SPH 8
+#endif
+constexpr uint32_t kGroupTri = RT3_GROUP_TRI, kGroupSph = RT3_GROUP_SPH;
 template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t GT = 1, uint32_t GS = 1>
 __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     static_assert(64 % GT == 0 && 64 % GS == 0, "group sizes must divide the wave");
@@ -862,6 +881,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
     uint32_t* pairs = s_pairs + (tid / 64u) * (2 * kPairCap);                  // (ray lane, row) pairs from the scan
     uint32_t* fpairs = pairs + kPairCap;                                       // GT > 1: (ray lane, face) pairs that passed their own bound
     unsigned long long* keys = s_key + (tid & ~63u);                           // this wave's 64 records
+    uint32_t* strip = A.pair_strips + ((size_t)blockIdx.x * (kTB / 64u) + tid / 64u) * kStripPairs;     // deferred member tests (GT, GS > 1)
 
     Path P;
     P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
@@ -895,11 +915,12 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
 #endif
         if (HAS_SPH && !HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);
         keys[lane] = HAS_SPH ? direct_tests(A, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, [&](uint32_t j) { return A.sph[j]; }) : kKeyNone;
-        uint32_t n_pairs = 0, n_fpairs = 0;
+        uint32_t n_pairs = 0, n_fpairs = 0, n_strip = 0;
 
         auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto group_tag, auto&& test, auto&& finish) {
             constexpr bool K32 = decltype(k32)::value;                          // spheres: 2 operand fragments (2 KiB) per row block, else 4
-            constexpr uint32_t GROUP = decltype(group_tag)::value;
+            constexpr bool GROUPED = decltype(group_tag)::value > 1;            // `test` is then the deferred (pair, valid, part) form
+            constexpr uint32_t LPPX = kLanesPerPair < decltype(group_tag)::value ? kLanesPerPair : decltype(group_tag)::value;
             constexpr uint32_t kVec = K32 ? 128u : 256u;
             constexpr uint32_t kTile = kTB * kTileLoads / kVec;                 // row blocks per tile (64 KiB at 1024 threads x 4 loads): 32 | 16
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
@@ -915,7 +936,13 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     if constexpr (K32) nz = mfma32k_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane, h0, 3);
                     else nz = mfma16_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
                     RT3_PHASE(pt_scan)
-                    push_pairs16<kTB, GROUP>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
+                    if constexpr (GROUPED) {
+                        push_pairs16_spill<kTB>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, [&](uint32_t v) {
+                            strip[n_strip + lane] = v;
+                            n_strip += 64u;
+                            if (n_strip + 64u > kStripPairs) { drain_strip<LPPX>(lane, strip, n_strip, test); n_strip = 0u; }    // (rare: 128 candidate rows per ray)
+                        });
+                    } else push_pairs16<kTB>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
                     RT3_PHASE(pt_push)
                     mfmas += hb * (K32 ? 8ull : 16ull);
                 }
@@ -943,29 +970,28 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
             } else {
                 // member m of a candidate group: the member's own bounding sphere in f32 — scan_tile's arithmetic with its margin
                 // (rt3_valu_scan.hpp; what k_trace and k_mode_r_fast filter with), on the unit direction the filter saw — then the list of survivors
-                struct FaceMember { float4 b; float ox, oy, oz, dx, dy, dz; uint32_t src, j; bool keep; };
-                auto group_test = group_test_of(
-                    [&](uint32_t pair, bool valid, uint32_t member) {
-                        FaceMember f;
-                        f.src = pair >> kPairLaneShift;
-                        f.j = (pair & ((1u << kPairLaneShift) - 1u)) * GT + member;
-                        const int sl = (int)f.src;
-                        f.ox = __shfl(ray.ox, sl); f.oy = __shfl(ray.oy, sl); f.oz = __shfl(ray.oz, sl);
-                        f.dx = __shfl(ux, sl); f.dy = __shfl(uy, sl); f.dz = __shfl(uz, sl);
-                        bound_tests += (unsigned long long)__popcll(__ballot(valid));
-                        f.keep = valid && f.j < A.n_tri;
-                        f.b = A.tri_bound[f.keep ? f.j : 0u];
-                        return f;
-                    },
-                    [&](const FaceMember& f) {
-                        const float cx = f.b.x - f.ox, cy = f.b.y - f.oy, cz = f.b.z - f.oz;
-                        const float h = fma_(cz, f.dz, fma_(cy, f.dy, cx * f.dx));
-                        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -f.b.w)));
+                constexpr uint32_t LPP = kLanesPerPair < GT ? kLanesPerPair : GT, MPL = GT / LPP;   // lanes per pair, members per lane
+                auto face_group = [&](uint32_t pair, bool valid, uint32_t part) {
+                    const uint32_t src = pair >> kPairLaneShift, g = pair & ((1u << kPairLaneShift) - 1u);
+                    const int sl = (int)src;
+                    const float sox = __shfl(ray.ox, sl), soy = __shfl(ray.oy, sl), soz = __shfl(ray.oz, sl);
+                    const float sdx = __shfl(ux, sl), sdy = __shfl(uy, sl), sdz = __shfl(uz, sl);
+                    bound_tests += (unsigned long long)__popcll(__ballot(valid)) * MPL;
+                    const uint32_t j0 = g * GT + part * MPL;
+                    float4 b[MPL];                                                  // this lane's members' bounds: MPL x 16 contiguous bytes
+#pragma unroll
+                    for (uint32_t m = 0; m < MPL; m++) b[m] = A.tri_bound[valid && j0 + m < A.n_tri ? j0 + m : 0u];
+#pragma unroll
+                    for (uint32_t m = 0; m < MPL; m++) {
+                        const uint32_t j = j0 + m;
+                        const float cx = b[m].x - sox, cy = b[m].y - soy, cz = b[m].z - soz;
+                        const float h = fma_(cz, sdz, fma_(cy, sdy, cx * sdx));
+                        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -b[m].w)));
                         const float disc = fma_(1e-5f, c, fma_(h, h, -c));
-                        const bool keep = f.keep && (__float_as_uint(disc) >> 31) == 0u;      // the sign bit, as scan_tile reads it
+                        const bool keep = valid && j < A.n_tri && (__float_as_uint(disc) >> 31) == 0u;      // the sign bit, as scan_tile reads it
                         const unsigned long long km = __ballot(keep);
-                        if (km == 0ull) return;
-                        if (keep) fpairs[n_fpairs + prefix_count(km)] = (f.src << kPairLaneShift) | f.j;
+                        if (km == 0ull) continue;
+                        if (keep) fpairs[n_fpairs + prefix_count(km)] = (src << kPairLaneShift) | j;
                         n_fpairs += (uint32_t)__popcll(km);
                         __builtin_amdgcn_wave_barrier();
                         if (n_fpairs >= 64u) {
@@ -973,9 +999,15 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                             face_test(fpairs[n_fpairs + lane], true);
                             __builtin_amdgcn_wave_barrier();
                         }
-                    });
-                pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, GT>(), group_test,
-                     [&]() { test_all_groups<GT>(lane, pairs, n_pairs, group_test); test_all(lane, fpairs, n_fpairs, face_test); });
+                    }
+                };
+                pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, GT>(), face_group,
+                     [&]() {
+                         if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                         drain_strip<LPP>(lane, strip, n_strip + n_pairs, face_group);
+                         n_strip = 0u; n_pairs = 0u;
+                         test_all(lane, fpairs, n_fpairs, face_test);
+                     });
             }
         }
         if (HAS_SPH) {
@@ -992,26 +1024,29 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                 pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, 1>(), test, [&]() { test_all(lane, pairs, n_pairs, test); });
             } else {
                 // member m of a candidate group: the exact test on the member's record (group order), keyed by the sphere's own index
-                struct SphereMember { float4 s; LaneRay r; uint32_t src, pos; bool ok; };
-                auto group_test = group_test_of(
-                    [&](uint32_t pair, bool valid, uint32_t member) {
-                        SphereMember m;
-                        m.src = pair >> kPairLaneShift;
-                        const uint32_t g = pair & ((1u << kPairLaneShift) - 1u);
-                        m.r = fetch_ray<false>(ray, m.src);
-                        exact += (unsigned long long)__popcll(__ballot(valid));
-                        m.ok = valid && g < A.n_sph_rows;
-                        m.pos = m.ok ? g * GS + member : 0u;
-                        m.s = A.sph_grp[m.pos];
-                        return m;
-                    },
-                    [&](const SphereMember& m) {
+                constexpr uint32_t LPP = kLanesPerPair < GS ? kLanesPerPair : GS, MPL = GS / LPP;   // lanes per pair, members per lane
+                auto sphere_group = [&](uint32_t pair, bool valid, uint32_t part) {
+                    const uint32_t src = pair >> kPairLaneShift, g = pair & ((1u << kPairLaneShift) - 1u);
+                    const LaneRay r = fetch_ray<false>(ray, src);
+                    exact += (unsigned long long)__popcll(__ballot(valid)) * MPL;
+                    const bool ok = valid && g < A.n_sph_rows;
+                    const uint32_t p0 = ok ? g * GS + part * MPL : 0u;
+                    float4 sm[MPL];                                                 // this lane's members' records (group order): MPL x 16 contiguous bytes
+#pragma unroll
+                    for (uint32_t m = 0; m < MPL; m++) sm[m] = A.sph_grp[p0 + m];
+#pragma unroll
+                    for (uint32_t m = 0; m < MPL; m++) {
                         float t;
-                        if (m.ok && sphere_root(m.s, m.r.ox, m.r.oy, m.r.oz, m.r.dx, m.r.dy, m.r.dz, A.t_min, t) && t < __builtin_inff())
-                            atomicMin(&keys[m.src], hit_key(t, 1u, A.sph_perm[m.pos]));
-                    });
-                pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, GS>(), group_test,
-                     [&]() { test_all_groups<GS>(lane, pairs, n_pairs, group_test); });
+                        if (ok && sphere_root(sm[m], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff())
+                            atomicMin(&keys[src], hit_key(t, 1u, A.sph_perm[p0 + m]));
+                    }
+                };
+                pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, GS>(), sphere_group,
+                     [&]() {
+                         if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                         drain_strip<LPP>(lane, strip, n_strip + n_pairs, sphere_group);
+                         n_strip = 0u; n_pairs = 0u;
+                     });
             }
         }
         __builtin_amdgcn_wave_barrier();
