@@ -216,6 +216,16 @@ int rt3_accum_upload(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* para
  * so that they run behind the shard's resolve kernel.  root == shard is allowed (single GPU). */
 int rt3_gather_rows(rt3_ctx* root, void* d_frame, rt3_ctx* shard, const void* d_tile,
                     const rt3_params* shard_params, void* stream);
+/* What rt3_gather_rows copies, as plain arithmetic (no device needed: a host can check or re-use it, tests/test_gather_plan.py): at most two
+ * strided copies of `rows` pieces of `row_bytes` bytes each, piece i from tile byte src_offset + i * src_pitch to frame byte dst_offset +
+ * i * dst_pitch.  Returns the number of copies written to out[0..1] (0: the shard owns no row) or RT3_E_ARG. */
+typedef struct rt3_gather_copy {
+    uint64_t dst_offset, src_offset;   /* bytes into the frame / into the compact tile */
+    uint64_t dst_pitch, src_pitch;     /* bytes between consecutive pieces */
+    uint64_t row_bytes;                /* bytes per piece (a whole row block of the shard, or the ragged last one) */
+    uint32_t rows;                     /* pieces */
+} rt3_gather_copy;
+int rt3_gather_plan(const rt3_params* shard_params, rt3_gather_copy out[2]);
 /* The context's own stream (a hipStream_t) and a wait for it — what a multi-device host needs around rt3_gather_rows. */
 void* rt3_stream(rt3_ctx* ctx);
 int   rt3_synchronize(rt3_ctx* ctx);

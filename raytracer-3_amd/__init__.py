@@ -58,6 +58,20 @@ class rt3_stats(C.Structure):
                 ("exact_tests", C.c_uint64), ("filter_tests", C.c_uint64), ("bound_tests", C.c_uint64)]
 
 
+class rt3_gather_copy(C.Structure):
+    _fields_ = [("dst_offset", C.c_uint64), ("src_offset", C.c_uint64), ("dst_pitch", C.c_uint64), ("src_pitch", C.c_uint64),
+                ("row_bytes", C.c_uint64), ("rows", C.c_uint32)]
+
+
+def gather_plan(params):
+    """The copies rt3_gather_rows issues for a shard, as a list of rt3_gather_copy (pure arithmetic, no device)."""
+    out = (rt3_gather_copy * 2)()
+    n = lib().rt3_gather_plan(C.byref(params), out)
+    if n < 0:
+        raise Fatal("rt3_gather_plan: bad shard parameters")
+    return [out[i] for i in range(n)]
+
+
 class Fatal(RuntimeError):
     """Mirror of CppDebugger::Fatal: every backend error is fatal (Main.cpp:305-308)."""
 
@@ -74,7 +88,7 @@ EXPORTS = [
     "rt3_mesh_begin", "rt3_mesh_put", "rt3_mesh_sphere", "rt3_mesh_commit", "rt3_mesh_download",
     "rt3_render_path_range", "rt3_render_path_range_device", "rt3_accum_download", "rt3_accum_upload", "rt3_gather_rows",
     "rt3_stream", "rt3_synchronize", "rt3_device_alloc_words", "rt3_device_free", "rt3_device_read_words", "rt3_debug_force_brute",
-    "rt3_abi_version", "rt3_debug_force_flat_filter",
+    "rt3_abi_version", "rt3_debug_force_flat_filter", "rt3_gather_plan",
 ]
 ABI_VERSION = 3          # RT3_ABI_VERSION of include/rt3.h these bindings (the STATS / PARAMS struct layouts below) were written against
 
@@ -127,7 +141,7 @@ def lib():
         "rt3_gather_rows": (i32, [vp, vp, vp, vp, vp, vp]), "rt3_stream": (vp, [vp]), "rt3_synchronize": (i32, [vp]),
         "rt3_device_alloc_words": (vp, [vp, u64]), "rt3_device_free": (None, [vp, vp]),
         "rt3_device_read_words": (i32, [vp, vp, u64, vp]), "rt3_debug_force_brute": (i32, [vp, i32]),
-        "rt3_abi_version": (u32, []), "rt3_debug_force_flat_filter": (i32, [vp, i32]),
+        "rt3_abi_version": (u32, []), "rt3_debug_force_flat_filter": (i32, [vp, i32]), "rt3_gather_plan": (i32, [vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)

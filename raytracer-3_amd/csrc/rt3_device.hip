@@ -971,6 +971,31 @@ int rt3_accum_upload(rt3_ctx* ctx, const rt3_camera* cam, const rt3_params* p, c
     return 0;
 }
 
+// The copies of rt3_gather_rows as plain arithmetic (no device): row block lb of the shard (tile_rows rows, compact in the tile) is row block
+// lb * tile_count + tile_index of the frame — one 2-D copy whose "rows" are whole row blocks, with the tile's block size as the source pitch and
+// tile_count times that as the destination pitch; only the frame's very last row block can be ragged, and it then travels as one more 1-D copy.
+int rt3_gather_plan(const rt3_params* p, rt3_gather_copy out[2]) {
+    if (!p || !out || p->width == 0 || p->height == 0) return RT3_E_ARG;
+    if (p->tile_count > 1 && (p->tile_rows == 0 || p->tile_index >= p->tile_count)) return RT3_E_ARG;
+    const uint64_t row_bytes = (uint64_t)p->width * 4;
+    if (p->tile_count <= 1) {
+        out[0] = rt3_gather_copy{ 0, 0, row_bytes * p->height, row_bytes * p->height, row_bytes * p->height, 1 };
+        return 1;
+    }
+    const uint32_t n_blocks_frame = (p->height + p->tile_rows - 1) / p->tile_rows;
+    if (p->tile_index >= n_blocks_frame) return 0;                                  // more shards than row blocks: this one owns nothing
+    const uint32_t my_blocks = (n_blocks_frame - 1 - p->tile_index) / p->tile_count + 1;
+    const uint32_t last_block = (my_blocks - 1) * p->tile_count + p->tile_index;    // frame index of this shard's last block
+    const uint32_t last_rows = std::min(p->tile_rows, p->height - last_block * p->tile_rows);
+    const uint32_t full = last_rows == p->tile_rows ? my_blocks : my_blocks - 1;
+    const uint64_t block_bytes = row_bytes * p->tile_rows;
+    int n = 0;
+    if (full) out[n++] = rt3_gather_copy{ (uint64_t)p->tile_index * block_bytes, 0, block_bytes * p->tile_count, block_bytes, block_bytes, full };
+    if (full != my_blocks) out[n++] = rt3_gather_copy{ (uint64_t)last_block * block_bytes, (uint64_t)full * block_bytes, row_bytes * last_rows, row_bytes * last_rows,
+                                                       row_bytes * last_rows, 1 };
+    return n;
+}
+
 // The gather of final pixels, device to device.  Row block lb of the shard (tile_rows rows, compact in d_tile)
 // is row block lb * tile_count + tile_index of the frame: one 2-D copy with the tile's pitch on one side and tile_count times that on
 // the other; only the frame's very last row block can be ragged, and it then travels as one more 1-D copy.
@@ -991,26 +1016,16 @@ int rt3_gather_rows(rt3_ctx* root, void* d_frame, rt3_ctx* shard, const void* d_
         (void)hipGetLastError();
         shard->peers_enabled.insert(root->device);
     }
-    const size_t row_bytes = (size_t)p->width * 4;
-    uint32_t* frame = (uint32_t*)d_frame;
-    const uint32_t* tile = (const uint32_t*)d_tile;
-    if (p->tile_count <= 1) {
-        RT3_HIP(hipMemcpyAsync(frame, tile, row_bytes * p->height, hipMemcpyDeviceToDevice, stream));
-        return 0;
+    rt3_gather_copy plan[2];
+    const int n_copies = rt3_gather_plan(p, plan);
+    if (n_copies < 0) return fail(ctx, RT3_E_ARG, "rt3_gather_rows: bad shard parameters");
+    uint8_t* frame = (uint8_t*)d_frame;
+    const uint8_t* tile = (const uint8_t*)d_tile;
+    for (int i = 0; i < n_copies; i++) {
+        const rt3_gather_copy& c = plan[i];
+        if (c.rows == 1) RT3_HIP(hipMemcpyAsync(frame + c.dst_offset, tile + c.src_offset, c.row_bytes, hipMemcpyDeviceToDevice, stream));
+        else RT3_HIP(hipMemcpy2DAsync(frame + c.dst_offset, c.dst_pitch, tile + c.src_offset, c.src_pitch, c.row_bytes, c.rows, hipMemcpyDeviceToDevice, stream));
     }
-    const uint32_t n_blocks_frame = (p->height + p->tile_rows - 1) / p->tile_rows;
-    if (p->tile_index >= n_blocks_frame) return 0;                                  // more shards than row blocks: this one owns nothing
-    const uint32_t my_blocks = (n_blocks_frame - 1 - p->tile_index) / p->tile_count + 1;
-    const uint32_t last_block = (my_blocks - 1) * p->tile_count + p->tile_index;    // frame index of this shard's last block
-    const uint32_t last_rows = std::min(p->tile_rows, p->height - last_block * p->tile_rows);
-    const uint32_t full = last_rows == p->tile_rows ? my_blocks : my_blocks - 1;
-    const size_t block_bytes = row_bytes * p->tile_rows;
-    if (full)
-        RT3_HIP(hipMemcpy2DAsync(frame + (size_t)p->tile_index * p->tile_rows * p->width, block_bytes * p->tile_count, tile, block_bytes,
-                                 block_bytes, full, hipMemcpyDeviceToDevice, stream));
-    if (full != my_blocks)
-        RT3_HIP(hipMemcpyAsync(frame + (size_t)last_block * p->tile_rows * p->width, tile + (size_t)full * p->tile_rows * p->width,
-                               row_bytes * last_rows, hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 

@@ -27,6 +27,7 @@ int rt3_render_path_range_device(rt3_ctx*, const rt3_camera*, const rt3_params*,
 int rt3_accum_download(rt3_ctx*, float*, float*, uint32_t*) { return RT3_E_DEVICE; }
 int rt3_accum_upload(rt3_ctx*, const rt3_camera*, const rt3_params*, const float*, const float*, uint32_t) { return RT3_E_DEVICE; }
 int rt3_gather_rows(rt3_ctx*, void*, rt3_ctx*, const void*, const rt3_params*, void*) { return RT3_E_DEVICE; }
+int rt3_gather_plan(const rt3_params*, rt3_gather_copy*) { return RT3_E_DEVICE; }
 void* rt3_stream(rt3_ctx*) { return nullptr; }
 int rt3_synchronize(rt3_ctx*) { return RT3_E_DEVICE; }
 void* rt3_device_alloc_words(rt3_ctx*, uint64_t) { return nullptr; }
