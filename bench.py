@@ -11,14 +11,14 @@ puts them at their frame rows with one indexed copy.  Total work is fixed, so sc
 N = 1: the rows go through rt3_gather_rows (the C ABI's device-to-device gather), no collective.
 
 Prints one JSON line (rank 0).  Beside the driver's fields:
-  roofline         the dominant kernel (k_trace_mfma32) against the matrix roofline: EXECUTED bf16 matrix FLOP
-                   (v_mfma_f32_16x16x32_bf16 instructions counted by the kernel itself x 16384) / kernel time measured
-                   live with HIP events on the launch stream, over the 2.5 PFLOP/s dense bf16 peak; `valu_issue` is the
-                   unit the kernel is actually bound by, `k64_equivalent_frac` the same test rate priced in round 1's
-                   K = 64 form (that kernel, RT3_MFMA_K64=1, executes twice the matrix work per test).  `live` names the
-                   fields measured in this run; `traffic` and `valu_issue` are hardware-counter figures that only
-                   rocprofv3 can collect — they are taken from the committed profile of this same command and carry
-                   its provenance, or are null when that profile was made from other kernel sources
+  roofline         the dominant kernel (k_trace_mfma32) against the unit it saturates.  `bound` names that unit: "valu_issue" — the vector ALU's
+                   instruction issue, (SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4-cycle issue slots over the SIMD-cycles of the launch, ONE definition
+                   everywhere (README, DESIGN, profiles/README.md, extra_workloads) — with achieved / peak / frac in issue slots per second,
+                   from the committed rocprofv3 --pmc passes of this same command (only rocprofv3 can collect them), gated by the fingerprint
+                   of the kernel sources they were collected on.  `mfma` beside it is measured LIVE in this run: executed bf16 matrix FLOP
+                   (v_mfma_f32_16x16x32_bf16 instructions counted by the kernel itself x 16384) / kernel time from HIP events on the launch
+                   stream, over the 2.5 PFLOP/s dense bf16 peak.  With a stale or missing profile `bound` falls back to "mfma" and the top-level
+                   achieved / peak / frac are the live matrix figures (the counters are then null, never reused on other code)
   algorithmic_equiv  SURVEY.md §8d's per-test figure (20 f32 FLOP per ray-sphere test) priced against the f32 peak — the
                    work a scalar formulation would do; NOT a roofline fraction of this kernel (it exceeds 1)
   cpu_baseline     the CPU oracle timed on this host's cores on a bounded sample of the same workload
@@ -45,7 +45,8 @@ FLOP_PER_MFMA = 32768.0              # v_mfma_f32_32x32x16_bf16: 32 x 32 x 16 mu
 PEAK_FP32_VALU_TFLOPS = 157.3        # MI355X_MICROARCH.md:41
 PEAK_HBM_GBS = 8000.0                # MI355X_MICROARCH.md:36
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense, MI355X_MICROARCH.md:43
-PMC_PROFILE = os.path.join("profiles", "r02_bench_pmc_k_trace.json")
+PMC_PROFILE = os.path.join("profiles", "r03_bench_pmc_k_trace.json")
+TILED_PMC_PROFILE = os.path.join("profiles", "r03_tiled_pmc.json")   # configs 4 / 5 / Mode R (tools/profile_tiled.sh)
 MODE_R_REFERENCE_CPU_S = 60.2        # SequentialRenderer (the reference's own CPU backend), built-in scene at 1920x1080:
                                      # SURVEY.md §6/§8d, measured by the survey on an 8-vCPU Xeon 2.1 GHz, 1 thread, -O2
 
@@ -142,16 +143,41 @@ def counters_from_profile(fingerprint):
                        pmc["WRITE_SIZE"]["sum_over_dispatches"] / pmc["WRITE_SIZE"]["dispatches"]) * 1024)
         cycles = pmc["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0                     # SIMD-cycles over all dispatches
         n_valu = pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] - pmc["SQ_INSTS_MFMA"]["sum_over_dispatches"]
+        disp = pmc["SQ_INSTS_VALU"]["dispatches"]
         valu = {"frac": round(n_valu * 4.0 / cycles, 3),
+                "issue_slots_per_launch": int(n_valu / disp), "simd_quad_cycles_per_launch": int(cycles / 4.0 / disp),
+                "mfma_pipe_busy": round(pmc["SQ_VALU_MFMA_BUSY_CYCLES"]["sum_over_dispatches"] / cycles, 3),
                 "active_inst_valu_ratio": round(pmc["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0 / cycles, 3),
-                "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] / pmc["SQ_INSTS_VALU"]["dispatches"]),
+                "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] / disp),
                 "source": src, "note": "frac = (SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 cycles / (1024 SIMDs x busy cycles): issue slots of the vector ALU "
-                                       "taken by its own (non-matrix) instructions, the resource this kernel saturates; active_inst_valu_ratio = "
-                                       "SQ_ACTIVE_INST_VALU x 4 / the same cycles counts the matrix instructions too, which issue beside the vector "
-                                       "ALU's, and can therefore exceed 1"}
+                                       "taken by its own (non-matrix) instructions, the resource this kernel saturates (tools/ubench_valu_rate.hip: a "
+                                       "v_alignbit / v_max / v_perm costs a SIMD 4.3 cycles with four waves resident, an FMA-class instruction 2.7-2.9, so "
+                                       "1 is not reachable with this mix); mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / the same SIMD-cycles; "
+                                       "active_inst_valu_ratio = SQ_ACTIVE_INST_VALU x 4 / the same cycles counts the matrix instructions too and is NOT "
+                                       "the issue fraction"}
         return traffic, src, valu
     except (KeyError, ZeroDivisionError):
         return None, "%s lacks FETCH_SIZE / WRITE_SIZE" % PMC_PROFILE, None
+
+
+def tiled_counters(fingerprint):
+    """VALU-issue fraction and matrix-pipe busy fraction of the kernels behind extra_workloads from profiles/r03_tiled_pmc.json (tools/profile_tiled.sh),
+    under the same rule as the headline's: only for the kernel sources they were collected on.  One definition: (VALU - MFMA instructions) x 4 / SIMD-cycles."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, TILED_PMC_PROFILE)))
+    except (OSError, ValueError):
+        return {}, "no committed profile (%s)" % TILED_PMC_PROFILE
+    made_from = pmc.get("_source_fingerprint")
+    if made_from != fingerprint:
+        return {}, "%s was collected on kernel sources %s, this build is %s: stale, not reported" % (TILED_PMC_PROFILE, made_from, fingerprint)
+    out = {}
+    for key, c in pmc.items():
+        if not isinstance(c, dict) or "SQ_BUSY_CYCLES" not in c:
+            continue
+        cycles = c["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0
+        out[key] = {"valu_issue": round((c["SQ_INSTS_VALU"]["sum_over_dispatches"] - c["SQ_INSTS_MFMA"]["sum_over_dispatches"]) * 4.0 / cycles, 3),
+                    "mfma_busy": round(c["SQ_VALU_MFMA_BUSY_CYCLES"]["sum_over_dispatches"] / cycles, 3)}
+    return out, "%s (rocprofv3 --pmc passes of tools/run_config.py, kernel sources %s)" % (TILED_PMC_PROFILE, made_from)
 
 
 def executed(st, k_slots=64):
@@ -172,22 +198,34 @@ def executed(st, k_slots=64):
         d["k64_equivalent_frac_of_bf16_peak"] = round(st.prim_tests * 128.0 / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
     if st.exact_tests:
         d["exact_tests_per_cast"] = round(st.exact_tests / max(1, st.ray_casts), 2)
+    if st.filter_tests and st.filter_tests != st.prim_tests:
+        # two-level filter: the matrix cores evaluated one row per GROUP of primitives; prim_tests / tests_per_s above are the
+        # brute-force-equivalent count (ray casts x primitives: what the reference's loop would execute), these are what was executed
+        d["filter"] = {"levels": 2, "filter_rows_per_cast": int(st.filter_tests // max(1, st.ray_casts)),
+                       "filter_tests_executed": int(st.filter_tests), "filter_tests_per_s": round(st.filter_tests / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
+                       "member_bound_tests_per_cast": round(st.bound_tests / max(1, st.ray_casts), 2),
+                       "note": "tests_per_s is brute-force EQUIVALENT (ray casts x primitives / kernel time); the matrix filter executed "
+                               "filter_tests_executed (ray, group-row) pairs, then member tests on the candidates"}
+        d["lane_efficiency"] = round(st.filter_tests * 2.0 * k_slots / (st.mfma_instructions * float(st.mfma_flop_per_instruction)), 4) if st.mfma_instructions else None
     return d
 
 
-def extra_workloads(rt3, r, np):
+def extra_workloads(rt3, r, np, fingerprint):
     """Short, driver-visible runs of the other workloads (kernel time = HIP events inside the C ABI; scene upload excluded)."""
     out = []
+    counters, counters_source = tiled_counters(fingerprint)
     empty_f, empty_v = np.zeros(0, rt3.GFACE), np.zeros((0, 4), np.float32)
     no_sph = (np.zeros((0, 4), np.float32), np.zeros(0, rt3.MATERIAL))
 
-    def path(name, cam, params, kernel, k_slots=64):
+    def path(name, cam, params, kernel, k_slots=64, counter_key=None):
         r.render_path(cam.c, params)                                     # warm-up: allocations, occupancy query
         r.render_path(cam.c, params)
         st = r.stats()
         d = {"workload": name, "kernel": kernel, "samples": int(st.samples), "ms": round(st.total_ms, 3),
              "msamples_per_s": round(st.samples / st.total_ms / 1e3, 2)}
         d.update(executed(st, k_slots))
+        d.update(counters.get(counter_key, {"valu_issue": None, "mfma_busy": None}))
+        d["counters_source"] = counters_source
         out.append(d)
 
     # Mode R: the reference's own render (SequentialRenderer::render) of its built-in scene, the one workload with a reference CPU time
@@ -213,7 +251,8 @@ def extra_workloads(rt3, r, np):
                     "k64_equivalent_frac_of_bf16_peak": round(2.0 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
                     "reference_cpu_s": MODE_R_REFERENCE_CPU_S, "speedup_vs_reference_cpu": round(MODE_R_REFERENCE_CPU_S / (ms * 1e-3), 0),
                     "note": "reference_cpu_s: the reference's SequentialRenderer on this frame, 1 thread, measured by the survey (SURVEY.md §6); "
-                            "pixels equal the reference's PPM SHA-256 (tests/test_gpu_mode_r.py)"})
+                            "pixels equal the reference's PPM SHA-256 (tests/test_gpu_mode_r.py)",
+                    "counters_source": counters_source, **counters.get("config_r", {"valu_issue": None, "mfma_busy": None})})
         r.set_mesh(empty_f, empty_v)
     # (config 3 runs the headline kernel on the headline scene: leaving it out keeps k_trace_mfma32's rocprofv3 average = the headline launch)
     # config 4: 100 000 spheres
@@ -223,14 +262,17 @@ def extra_workloads(rt3, r, np):
     cam = rt3.Camera().look_at(1920, 1080, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
     path("config 4: 100 000 spheres, 1920x1080, 16 of 256 spp, depth 50", cam,
          rt3.make_params(1920, 1080, spp=16, max_depth=50, flags=rt3.FLAG_GAMMA2),
-         "k_trace_mfma_tiled<spheres> (K = 32 filter: one v_mfma_f32_16x16x32_bf16 per 16 x 16 tests)", k_slots=32)
+         "k_trace_mfma_tiled<spheres, groups of 8> (two-level filter: K = 32 matrix filter over group rows, member tests on the candidates)", k_slots=32,
+         counter_key="config_4")
     # config 5: Cornell-style box, 47 106 triangles, emissive quad
     faces, verts, fm = rt3.scene_cornell(64)
     r.set_spheres(*no_sph)
     r.set_mesh(faces, verts, fm)
     cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
     path("config 5: Cornell-style box, %d triangles, emissive quad, 1024x1024, 32 of 2048 spp, depth 50" % len(faces), cam,
-         rt3.make_params(1024, 1024, spp=32, max_depth=50, flags=rt3.FLAG_GAMMA2 | rt3.FLAG_BLACK_BACKGROUND), "k_trace_mfma_tiled<faces> (K = 32 filter: one v_mfma_f32_16x16x32_bf16 per 16 x 16 tests)", k_slots=32)
+         rt3.make_params(1024, 1024, spp=32, max_depth=50, flags=rt3.FLAG_GAMMA2 | rt3.FLAG_BLACK_BACKGROUND),
+         "k_trace_mfma_tiled<faces, groups of 8> (two-level filter: K = 32 matrix filter over group rows, member bound tests, exact tests on the survivors)",
+         k_slots=32, counter_key="config_5")
     r.set_mesh(empty_f, empty_v)
     return out
 
@@ -336,25 +378,35 @@ def main():
         traffic, traffic_source, valu = counters_from_profile(fingerprint) if full_workload else (None, "not the profiled workload", None)
         if st.mfma_instructions:
             k32 = st.mfma_flop_per_instruction == 16384                      # k_trace_mfma32 (default) | k_trace_mfma (RT3_MFMA_K64=1, round 1's form)
-            roofline = {"bound": "mfma", "kernel": "k_trace_mfma32" if k32 else "k_trace_mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(mfma_tf / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                        "kernel_ms": round(k_ms, 3), "launches_per_step": launches, "mfma_instructions_per_launch": int(st.mfma_instructions / n_launch),
-                        "mfma_instruction": "v_mfma_f32_16x16x32_bf16" if k32 else "v_mfma_f32_32x32x16_bf16",
-                        "flop_per_mfma_instruction": int(st.mfma_flop_per_instruction), "filter_k": 32 if k32 else 64,
-                        # the same test rate priced in round 1's K = 64 form (128 FLOP per test): for comparisons across rounds, not executed work
-                        "k64_equivalent_frac": round(st.prim_tests * 128.0 / n_launch / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if k_ms > 0 else 0.0,
-                        "live": ["achieved", "frac", "kernel_ms", "mfma_instructions_per_launch (counted by the kernel)"],
-                        "valu_issue": valu, "kernel_sources": fingerprint,
-                        "note": "EXECUTED work of the dominant kernel: matrix wave-instructions x FLOP per instruction / kernel time (HIP events on the "
-                                "launch stream) over the dense bf16 peak.  The kernel evaluates the discriminant of every (ray, sphere) pair as a "
-                                "split-bf16 contraction on the matrix cores (DESIGN.md 5.2b) and is bound by vector-ALU instruction issue beside it "
-                                "(valu_issue: one v_alignbit per pair decodes the sign bits).  Round 2's K = 32 form executes HALF the matrix work per "
-                                "test of round 1's K = 64 form, so this fraction fell (0.50 -> 0.32) while the kernel got 20 % faster: the chip "
-                                "throttles less (2.0-2.2 GHz -> ~2.3 GHz) and an issue-bound kernel runs at the clock"}
+            mfma = {"achieved": round(mfma_tf, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "mfma_instructions_per_launch": int(st.mfma_instructions / n_launch),
+                    "mfma_instruction": "v_mfma_f32_16x16x32_bf16" if k32 else "v_mfma_f32_32x32x16_bf16",
+                    "flop_per_mfma_instruction": int(st.mfma_flop_per_instruction), "filter_k": 32 if k32 else 64,
+                    # the same test rate priced in round 1's K = 64 form (128 FLOP per test): for comparisons across rounds, not executed work
+                    "k64_equivalent_frac": round(st.prim_tests * 128.0 / n_launch / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if k_ms > 0 else 0.0,
+                    "live": True,
+                    "note": "EXECUTED matrix work, measured in this run: wave-instructions counted by the kernel x FLOP per instruction / kernel time (HIP "
+                            "events on the launch stream) over the dense bf16 peak.  The K = 32 filter (DESIGN.md 5.2b) needs half the matrix work per "
+                            "test of round 1's K = 64 form; the matrix pipe is about a third busy, the vector ALU beside it decodes one sign bit per pair"}
+            common = {"kernel": "k_trace_mfma32" if k32 else "k_trace_mfma", "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(k_ms, 3),
+                      "launches_per_step": launches, "kernel_sources": fingerprint, "mfma": mfma}
+            if valu is not None:
+                roofline = dict(common, bound="valu_issue", achieved=valu["issue_slots_per_launch"], peak=valu["simd_quad_cycles_per_launch"],
+                                unit="4-cycle vector-ALU issue slots per launch (peak: SIMD-cycles / 4)", frac=valu["frac"], valu_issue=valu,
+                                live=["kernel_ms", "mfma (all of it)"],
+                                note="bound = the unit this kernel saturates: the vector ALU's own instructions fill `frac` of all 4-cycle issue slots of "
+                                     "the launch (hardware counters of the committed rocprofv3 passes of this command, valid for these kernel sources "
+                                     "only); the executed matrix fraction, measured live, is under `mfma`")
+            else:
+                roofline = dict(common, bound="mfma", achieved=mfma["achieved"], peak=mfma["peak"], unit=mfma["unit"], frac=mfma["frac"], valu_issue=None,
+                                live=["achieved", "frac", "kernel_ms", "mfma"],
+                                note="no valid counter profile for this run (%s): the live executed-matrix fraction stands in; the kernel's binding "
+                                     "unit is vector-ALU issue (see profiles/README.md)" % traffic_source)
         else:
-            roofline = {"bound": "mfma", "kernel": "k_trace (vector-ALU scan, RT3_NO_MFMA / RT3_BRUTE)", "achieved": 0.0, "peak": PEAK_BF16_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": 0.0, "traffic": None, "traffic_source": "A/B build, not profiled", "kernel_ms": round(k_ms, 3),
-                        "launches_per_step": launches, "live": ["kernel_ms"], "note": "no matrix instructions issued by this kernel selection"}
+            roofline = {"bound": "valu_issue", "kernel": "k_trace (vector-ALU scan, RT3_NO_MFMA / RT3_BRUTE)", "achieved": None, "peak": None,
+                        "unit": "4-cycle vector-ALU issue slots per launch", "frac": None, "traffic": None, "traffic_source": "A/B build, not profiled",
+                        "kernel_ms": round(k_ms, 3), "launches_per_step": launches, "live": ["kernel_ms"], "mfma": None,
+                        "note": "no matrix instructions issued by this kernel selection (A/B reference)"}
         out = {
             "metric": "Msamples/sec (pixels x spp) at %dx%dx%dspp" % (W, H, args.spp),
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -388,7 +440,7 @@ def main():
             f.data[:] = g.frame.cpu().numpy().view(np.uint32)
             f.to_ppm(args.save_ppm)
         if world == 1 and full_workload and not args.no_extra:
-            out["extra_workloads"] = extra_workloads(rt3, r, np)
+            out["extra_workloads"] = extra_workloads(rt3, r, np, fingerprint)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -60,7 +60,7 @@ struct rt3_ctx {
     float4* d_sph = nullptr; uint32_t* d_sph_frag = nullptr; uint32_t* d_sph_frag32 = nullptr; float sph_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t n_direct = 0; uint32_t direct[4] = { 0, 0, 0, 0 }; float tri_centre[3] = { 0.0f, 0.0f, 0.0f }; uint32_t* d_box = nullptr; uint32_t* d_tri_frag_r = nullptr; float* d_sph_invr = nullptr; float4* d_sph_mat = nullptr; uint32_t* d_sph_kind = nullptr;
 
     // group rows of the two-level filter: faces in face order, spheres in the order of a spatial median split
-    u32x4* d_tri_gfrag = nullptr; uint32_t n_tri_groups = 0;
+    u32x4* d_tri_gfrag = nullptr; float4* d_tri_grp = nullptr; uint32_t* d_tri_perm = nullptr; uint32_t n_tri_groups = 0;
     u32x4* d_sph_gfrag = nullptr; float4* d_sph_grp = nullptr; uint32_t* d_sph_perm = nullptr; uint32_t n_sph_groups = 0;
     uint32_t* d_strips = nullptr; size_t strip_entries = 0;          // deferred member tests: kStripPairs pairs per wave of the grid
 
@@ -295,20 +295,13 @@ uint32_t sphere_direct_list(const float* center_radius, uint32_t n, const float 
     return count;
 }
 
-// Group order of the spheres for the two-level filter: a median split of the centres along the longest axis of their box,
-// repeated until a part holds at most `group` spheres; the left part of every split is a multiple of `group`, so that only the very last
-// group is short.  Consecutive runs of `group` entries of the result are the groups; 0xFFFFFFFF pads the last one.  Spheres on the `direct`
-// list (tested for every ray anyway) and spheres whose record is not finite (no exact test can accept them) stay out.
+// Group order for the two-level filter: a median split of the centres along the longest axis of their box, repeated until a
+// part holds at most `group` primitives; the left part of every split is a multiple of `group`, so that only the very last group is short.
+// Consecutive runs of `group` entries of the result are the groups; 0xFFFFFFFF pads the last one.  Spheres on the `direct` list (tested for
+// every ray anyway) and spheres whose record is not finite (no exact test can accept them) stay out.
 // Any order is correct — the nearest-hit key carries the sphere's own index, and the minimum over the keys does not depend on the order the
 // pairs are tested in — a compact one keeps the groups' bounding spheres small.
-std::vector<uint32_t> sphere_group_order(const float* center_radius, uint32_t n, const uint32_t* direct, uint32_t n_direct, uint32_t group) {
-    std::vector<uint32_t> ids;
-    ids.reserve(n);
-    for (uint32_t i = 0; i < n; i++) {
-        const float* s = center_radius + 4 * (size_t)i;
-        if (is_direct(i, direct, n_direct) || !std::isfinite(s[0]) || !std::isfinite(s[1]) || !std::isfinite(s[2]) || !std::isfinite(s[3] * s[3])) continue;
-        ids.push_back(i);
-    }
+void median_split_order(std::vector<uint32_t>& ids, const float* xyz_stride4, uint32_t group) {
     struct Part { size_t begin, end; };
     std::vector<Part> stack;
     stack.push_back({ 0, ids.size() });
@@ -319,16 +312,43 @@ std::vector<uint32_t> sphere_group_order(const float* center_radius, uint32_t n,
         if (count <= group) continue;
         float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
         for (size_t k = part.begin; k < part.end; k++)
-            for (int a = 0; a < 3; a++) { const float c = center_radius[4 * (size_t)ids[k] + a]; lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
+            for (int a = 0; a < 3; a++) { const float c = xyz_stride4[4 * (size_t)ids[k] + a]; lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
         int axis = 0;
         for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
         size_t half = (count / 2 + group - 1) / group * group;
         if (half >= count) half = count - group;                    // (count > group here)
         std::nth_element(ids.begin() + part.begin, ids.begin() + part.begin + half, ids.begin() + part.end,
-                         [&](uint32_t x, uint32_t y) { return center_radius[4 * (size_t)x + axis] < center_radius[4 * (size_t)y + axis]; });
+                         [&](uint32_t x, uint32_t y) { return xyz_stride4[4 * (size_t)x + axis] < xyz_stride4[4 * (size_t)y + axis]; });
         stack.push_back({ part.begin + half, part.end });
         stack.push_back({ part.begin, part.begin + half });
     }
+}
+std::vector<uint32_t> sphere_group_order(const float* center_radius, uint32_t n, const uint32_t* direct, uint32_t n_direct, uint32_t group) {
+    std::vector<uint32_t> ids;
+    ids.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float* s = center_radius + 4 * (size_t)i;
+        if (is_direct(i, direct, n_direct) || !std::isfinite(s[0]) || !std::isfinite(s[1]) || !std::isfinite(s[2]) || !std::isfinite(s[3] * s[3])) continue;
+        ids.push_back(i);
+    }
+    median_split_order(ids, center_radius, group);
+    ids.resize((ids.size() + group - 1) / group * group, 0xFFFFFFFFu);
+    return ids;
+}
+// The same for faces, from their bounding spheres (cx, cy, cz, r^2 as k_commit_mesh wrote them): a mesh may list its faces in any order (the
+// reference's teddy.obj does), and groups of faces that merely follow each other in the file would span the model.  Faces without a bounded hit
+// region (r^2 >= 3e38: always candidates) go last, in groups of their own, so that they make only their own rows always-candidates.
+std::vector<uint32_t> face_group_order(const float4* bounds, uint32_t n, uint32_t group) {
+    std::vector<uint32_t> ids, unbounded;
+    ids.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const float4 b = bounds[i];
+        if (std::isfinite(b.x) && std::isfinite(b.y) && std::isfinite(b.z) && b.w >= 0.0f && b.w < 3e38f) ids.push_back(i);
+        else unbounded.push_back(i);
+    }
+    median_split_order(ids, reinterpret_cast<const float*>(bounds), group);
+    ids.resize((ids.size() + group - 1) / group * group, 0xFFFFFFFFu);
+    ids.insert(ids.end(), unbounded.begin(), unbounded.end());
     ids.resize((ids.size() + group - 1) / group * group, 0xFFFFFFFFu);
     return ids;
 }
@@ -413,7 +433,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r,
-                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips };
+                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips, ctx->d_tri_grp, ctx->d_tri_perm };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -490,7 +510,7 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
     for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in,
-                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag })
+                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm })
         if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
     ctx->n_faces = 0; ctx->n_tri_groups = 0;
     if (n == 0) return 0;
@@ -533,22 +553,30 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
                        ctx->cap_verts, ctx->d_face_mats_in, ctx->d_tri, ctx->d_tri_bound, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_error,
                        (u32x4*)ctx->d_tri_frag_r, n_frag_rows, (const uint32_t*)ctx->d_box, 0.5f);
     RT3_HIP(hipGetLastError());
-    // rows of the two-level filter: the bounding sphere of every kGroupTri consecutive faces, from the faces' own bounds (meshes come in a
-    // coherent order: a tessellation emits neighbours one after the other)
-    ctx->n_tri_groups = (n + kGroupTri - 1u) / kGroupTri;
-    {
-        const uint32_t n_group_rows = (ctx->n_tri_groups + 31u) / 32u * 32u;
-        RT3_HIP(hipMalloc((void**)&ctx->d_tri_gfrag, (size_t)n_group_rows * 4 * sizeof(u32x4)));
-        hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_bound, n, kGroupTri,
-                           n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_gfrag);
-        RT3_HIP(hipGetLastError());
-    }
     uint32_t err = 0, box[6];
     RT3_HIP(hipMemcpyAsync(&err, ctx->d_error, 4, hipMemcpyDeviceToHost, ctx->stream));
     RT3_HIP(hipMemcpyAsync(box, ctx->d_box, sizeof(box), hipMemcpyDeviceToHost, ctx->stream));
     RT3_HIP(hipStreamSynchronize(ctx->stream));
     box_centre(box, ctx->tri_centre);
     if (err) return fail(ctx, RT3_E_ARG, "a face references a vertex out of range");
+    // rows of the two-level filter: groups of kGroupTri faces in the order of a spatial median split of their bounds (read back once per commit:
+    // 16 bytes per face); the members' bounds in group order + the face index of each
+    {
+        std::vector<float4> bounds(n);
+        RT3_HIP(hipMemcpy(bounds.data(), ctx->d_tri_bound, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+        const std::vector<uint32_t> order = face_group_order(bounds.data(), n, kGroupTri);
+        std::vector<float4> grp(order.size(), kPadSphere);
+        for (size_t k = 0; k < order.size(); k++) if (order[k] != 0xFFFFFFFFu) grp[k] = bounds[order[k]];
+        int rc;
+        if ((rc = upload(ctx, &ctx->d_tri_grp, grp)) || (rc = upload(ctx, &ctx->d_tri_perm, order))) return rc;
+        ctx->n_tri_groups = (uint32_t)(order.size() / kGroupTri);
+        const uint32_t n_group_rows = (ctx->n_tri_groups + 31u) / 32u * 32u;
+        RT3_HIP(hipMalloc((void**)&ctx->d_tri_gfrag, (size_t)n_group_rows * 4 * sizeof(u32x4)));
+        hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_grp, (uint32_t)order.size(),
+                           kGroupTri, n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_gfrag);
+        RT3_HIP(hipGetLastError());
+        RT3_HIP(hipStreamSynchronize(ctx->stream));                 // a render may come on another stream
+    }
     ctx->n_faces = n;
     return 0;
 }
@@ -817,7 +845,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     const bool grouped = kGroupTri > 1 && kGroupSph > 1 && !ctx->force_flat && !getenv("RT3_NO_GROUPS");
     A.n_tri_rows = grouped ? ctx->n_tri_groups : ctx->n_faces;
     A.n_sph_rows = grouped ? ctx->n_sph_groups : ctx->n_sph;
-    A.sph_grp = ctx->d_sph_grp; A.sph_perm = ctx->d_sph_perm;
+    A.sph_grp = ctx->d_sph_grp; A.sph_perm = ctx->d_sph_perm; A.tri_grp = ctx->d_tri_grp; A.tri_perm = ctx->d_tri_perm;
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
     TraceKernel plain = nullptr;
     TiledKernel tiled = nullptr;

@@ -131,10 +131,10 @@ struct TraceArgs {
     // rows can never be candidates (sphere_direct_list in rt3_device.hip).  Matrix-filter kernels only.
     uint32_t n_direct; uint32_t direct[4];
     // Two-level filter of k_trace_mfma_tiled: with a group size G > 1 a row of the matrix filter is the bounding sphere of G
-    // primitives.  Faces are grouped in face order (row g = faces [g G, (g + 1) G)); spheres in the order of a spatial median split
-    // (rt3_set_spheres): sph_grp holds their (cx, cy, cz, r^2) records in GROUP order, sph_perm the sphere index of each (0xFFFFFFFF: padding,
-    // and the direct spheres, which are not in any group).  *_rows: rows the pass scans (= primitives when G is 1).
-    const float4* sph_grp; const uint32_t* sph_perm; uint32_t n_sph_rows, n_tri_rows;
+    // primitives, grouped in the order of a spatial median split (rt3_set_spheres / rt3_mesh_commit): *_grp holds the members' (cx, cy, cz, r^2)
+    // records — the spheres themselves, the faces' bounding spheres — in GROUP order (row g = entries [g G, (g + 1) G)), *_perm the primitive
+    // index of each (0xFFFFFFFF: padding; the direct spheres are in no group).  *_rows: rows the pass scans (= primitives when G is 1).
+    const float4* sph_grp; const uint32_t* sph_perm; const float4* tri_grp; const uint32_t* tri_perm; uint32_t n_sph_rows, n_tri_rows;
     uint32_t* pair_strips;   // [wave of the grid][kStripPairs]: candidate (ray lane, row) pairs set aside for the end of a pass (deferred member tests)
     uint32_t* work_counter;
     unsigned long long* cast_counter;

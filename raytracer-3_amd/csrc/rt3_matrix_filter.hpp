@@ -977,21 +977,22 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     const float sox = __shfl(ray.ox, sl), soy = __shfl(ray.oy, sl), soz = __shfl(ray.oz, sl);
                     const float sdx = __shfl(ux, sl), sdy = __shfl(uy, sl), sdz = __shfl(uz, sl);
                     bound_tests += (unsigned long long)__popcll(__ballot(valid)) * MPL;
-                    const uint32_t j0 = g * GT + part * MPL;
-                    float4 b[MPL];                                                  // this lane's members' bounds: MPL x 16 contiguous bytes
+                    const uint32_t p0 = valid && g < A.n_tri_rows ? g * GT + part * MPL : 0u;
+                    float4 b[MPL];                                                  // this lane's members' bounds (group order): MPL x 16 contiguous bytes
 #pragma unroll
-                    for (uint32_t m = 0; m < MPL; m++) b[m] = A.tri_bound[valid && j0 + m < A.n_tri ? j0 + m : 0u];
+                    for (uint32_t m = 0; m < MPL; m++) b[m] = A.tri_grp[p0 + m];
 #pragma unroll
                     for (uint32_t m = 0; m < MPL; m++) {
-                        const uint32_t j = j0 + m;
                         const float cx = b[m].x - sox, cy = b[m].y - soy, cz = b[m].z - soz;
                         const float h = fma_(cz, sdz, fma_(cy, sdy, cx * sdx));
                         const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -b[m].w)));
                         const float disc = fma_(1e-5f, c, fma_(h, h, -c));
-                        const bool keep = valid && j < A.n_tri && (__float_as_uint(disc) >> 31) == 0u;      // the sign bit, as scan_tile reads it
+                        // the sign bit, as scan_tile reads it (padding: r^2 = -1e30); a face without a bounded hit region (r^2 = 3e38, possibly a
+                        // non-finite centre) goes to the exact test whatever the arithmetic above made of it
+                        const bool keep = valid && g < A.n_tri_rows && ((__float_as_uint(disc) >> 31) == 0u || b[m].w >= 3e38f);
                         const unsigned long long km = __ballot(keep);
                         if (km == 0ull) continue;
-                        if (keep) fpairs[n_fpairs + prefix_count(km)] = (src << kPairLaneShift) | j;
+                        if (keep) fpairs[n_fpairs + prefix_count(km)] = (src << kPairLaneShift) | A.tri_perm[p0 + m];
                         n_fpairs += (uint32_t)__popcll(km);
                         __builtin_amdgcn_wave_barrier();
                         if (n_fpairs >= 64u) {

@@ -213,8 +213,8 @@ __global__ void k_group_frags(const float4* __restrict__ bounds, uint32_t n_entr
         const uint64_t j = (uint64_t)g * group + m;
         if (j >= n_entries) break;
         const float4 b = bounds[j];
+        if (b.w >= 3e38f) { always = true; continue; }              // (whatever its centre is)
         if (!(b.w >= 0.0f) || !(b.x - b.x == 0.0f) || !(b.y - b.y == 0.0f) || !(b.z - b.z == 0.0f)) continue;
-        if (!(b.w < 3e38f)) { always = true; continue; }
         sx += b.x; sy += b.y; sz += b.z; members++;
     }
     float fx = 0.0f, fy = 0.0f, fz = 0.0f, kj = kNeverCandidate;

@@ -68,15 +68,82 @@ def test_bench_line_has_every_field_of_the_contract():
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 1920 * 1080 * 8 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "mfma"):
         assert key in r, key
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # 8 spp is not the profiled workload: hardware counters are never guessed, so the binding unit's figures are absent and the live
+    # executed-matrix fraction stands in for achieved / peak / frac (bound "mfma"); at the full workload with a fresh profile bound is "valu_issue"
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.0 < r["frac"] <= 1.0                                  # a roofline fraction: executed work over the peak of the unit that does it
-    assert r["peak"] == 2500.0 and "achieved" in r["live"] and "traffic_source" in r
-    assert r["traffic"] is None                                    # not the profiled workload (8 spp): counters are never guessed
+    assert r["peak"] == 2500.0 and "achieved" in r["live"] and "traffic_source" in r and r["valu_issue"] is None
+    assert r["traffic"] is None
+    m = r["mfma"]
+    assert m["live"] is True and m["filter_k"] == 32 and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3 and m["frac"] == r["frac"]
     a = d["algorithmic_equiv"]
     assert a["flop_per_test"] == 20.0 and abs(a["tflops"] - d["prim_tests"] * 20.0 / (r["kernel_ms"] * 1e-3) / 1e12) / a["tflops"] < 0.02
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"]
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    B = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(B)
+    return B
+
+
+def test_the_line_names_what_binds_with_one_definition(tmp_path, monkeypatch):
+    """With a counter profile of the running kernel sources `roofline.bound` is the saturated unit, "valu_issue", defined as (SQ_INSTS_VALU -
+    SQ_INSTS_MFMA) x 4 / SIMD-cycles — the same expression for the headline (counters_from_profile) and for the tiled kernels (tiled_counters);
+    SQ_ACTIVE_INST_VALU, which counts the matrix instructions too, is reported beside it under its own name and never as the issue fraction."""
+    B = _load_bench()
+    monkeypatch.setattr(B, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "raytracer-3_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "raytracer-3_amd" / "csrc" / "k.hip").write_text("__global__ void k() {}\n")
+    fp = B.source_fingerprint()
+    one = lambda v, n=1: {"sum_over_dispatches": float(v), "dispatches": n}
+    cycles_simd = 4.0e9                                            # SIMD-cycles of the launch = SQ_BUSY_CYCLES / 32 * 1024
+    pmc = {"_source_fingerprint": fp, "FETCH_SIZE": one(1000), "WRITE_SIZE": one(500), "SQ_BUSY_CYCLES": one(cycles_simd / 1024 * 32),
+           "SQ_INSTS_VALU": one(1.0e9), "SQ_INSTS_MFMA": one(1.0e8), "SQ_ACTIVE_INST_VALU": one(1.05e9), "SQ_VALU_MFMA_BUSY_CYCLES": one(1.6e9)}
+    (tmp_path / B.PMC_PROFILE).write_text(json.dumps(pmc))
+    traffic, why, valu = B.counters_from_profile(fp)
+    assert traffic == int((2 * 1000 + 500) * 1024)                # FETCH_SIZE doubled (gfx950), KiB
+    assert valu["frac"] == round((1.0e9 - 1.0e8) * 4 / cycles_simd, 3) == 0.9
+    assert valu["mfma_pipe_busy"] == 0.4 and valu["active_inst_valu_ratio"] == 1.05 and valu["active_inst_valu_ratio"] != valu["frac"]
+    assert valu["issue_slots_per_launch"] == int(9.0e8) and valu["simd_quad_cycles_per_launch"] == int(1.0e9)
+    tiled = {"_source_fingerprint": fp, "config_5": dict(pmc, _x=0)}
+    tiled["config_5"].pop("_source_fingerprint")
+    tiled["config_5"].pop("_x")
+    (tmp_path / B.TILED_PMC_PROFILE).write_text(json.dumps(tiled))
+    counters, src = B.tiled_counters(fp)
+    assert counters["config_5"] == {"valu_issue": 0.9, "mfma_busy": 0.4} and "stale" not in src
+    counters, src = B.tiled_counters("0" * 16)
+    assert counters == {} and "stale" in src
+
+
+@pytest.mark.gpu
+def test_full_workload_line_carries_the_binding_unit_and_the_extra_workloads(tmp_path):
+    """The default command (what the driver runs) at reduced steps: extra_workloads are there with the two-level filter's executed / equivalent counts,
+    and `roofline` follows the fingerprint rule — "valu_issue" with counter figures when profiles/r03_bench_pmc_k_trace.json belongs to this build, the
+    live matrix figures otherwise."""
+    p = run_bench("--steps", "1", "--warmup", "1", "--cpu-seconds", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    r = d["roofline"]
+    B = _load_bench()
+    fresh = B.counters_from_profile(B.source_fingerprint())[2] is not None
+    assert r["bound"] == ("valu_issue" if fresh else "mfma")
+    if fresh:
+        assert r["frac"] == r["valu_issue"]["frac"] and 0.5 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3 and r["traffic"] > 1e10
+    assert r["mfma"]["live"] is True and 0.2 < r["mfma"]["frac"] < 0.6
+    ew = {w["workload"].split(":")[0]: w for w in d["extra_workloads"]}
+    assert set(ew) == {"Mode R", "config 4", "config 5"}
+    for name in ("config 4", "config 5"):
+        w = ew[name]
+        f = w["filter"]
+        assert f["levels"] == 2 and f["filter_tests_executed"] * 7 < w["prim_tests"] and w["tests_per_s"] > 3e13       # brute-force equivalent
+        assert "valu_issue" in w and "mfma_busy" in w and "counters_source" in w
+    assert ew["config 5"]["filter"]["member_bound_tests_per_cast"] > 0 and ew["config 4"]["exact_tests_per_cast"] > 100
