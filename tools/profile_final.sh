@@ -4,7 +4,7 @@
 # rocprofv3 gets `python3 bench.py ...` directly after `--`; counters are collected in their own passes (no trace domains).
 export TMPDIR=/tmp
 out=gpurun_out/final
-export RT3_PROFILE_TAG=${RT3_PROFILE_TAG:-r02}
+export RT3_PROFILE_TAG=${RT3_PROFILE_TAG:-r03}
 rm -rf $out && mkdir -p $out
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
