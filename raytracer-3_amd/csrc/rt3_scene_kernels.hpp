@@ -220,13 +220,30 @@ __global__ void k_group_frags(const float4* __restrict__ bounds, uint32_t n_entr
     float fx = 0.0f, fy = 0.0f, fz = 0.0f, kj = kNeverCandidate;
     if (always) kj = kAlwaysCandidate;
     else if (members != 0) {
-        const double cx = sx / members, cy = sy / members, cz = sz / members;
+        // centre: towards the smallest enclosing sphere of the members' spheres (Badoiu-Clarkson: start at the mean, step 1 / (k + 1) towards the
+        // farthest member, 32 times) — R^2 comes out a quarter smaller than about the mean on the 100 000-sphere scene, and with it the candidates;
+        // any centre is correct, R below is measured from whichever one this ends on
+        double cx = sx / members, cy = sy / members, cz = sz / members;
+        auto usable = [](const float4& b) { return b.w >= 0.0f && b.w < 3e38f && b.x - b.x == 0.0f && b.y - b.y == 0.0f && b.z - b.z == 0.0f; };
+        for (int it = 1; it <= 32 && members > 1; it++) {
+            double far = -1.0, tx = cx, ty = cy, tz = cz;
+            for (uint32_t m = 0; m < group; m++) {
+                const uint64_t j = (uint64_t)g * group + m;
+                if (j >= n_entries) break;
+                const float4 b = bounds[j];
+                if (!usable(b)) continue;
+                const double ddx = b.x - cx, ddy = b.y - cy, ddz = b.z - cz, d = sqrt(ddx * ddx + ddy * ddy + ddz * ddz) + sqrt((double)b.w);
+                if (d > far) { far = d; tx = b.x; ty = b.y; tz = b.z; }
+            }
+            const double step = 1.0 / (it + 1);
+            cx += (tx - cx) * step; cy += (ty - cy) * step; cz += (tz - cz) * step;
+        }
         double R = 0.0;
         for (uint32_t m = 0; m < group; m++) {
             const uint64_t j = (uint64_t)g * group + m;
             if (j >= n_entries) break;
             const float4 b = bounds[j];
-            if (!(b.w >= 0.0f) || !(b.x - b.x == 0.0f) || !(b.y - b.y == 0.0f) || !(b.z - b.z == 0.0f) || !(b.w < 3e38f)) continue;
+            if (!usable(b)) continue;
             const double ddx = b.x - cx, ddy = b.y - cy, ddz = b.z - cz;
             R = fmax(R, sqrt(ddx * ddx + ddy * ddy + ddz * ddz) + sqrt((double)b.w));
         }
