@@ -62,6 +62,7 @@ struct rt3_ctx {
     // group rows of the two-level filter: faces in face order, spheres in the order of a spatial median split
     u32x4* d_tri_gfrag = nullptr; float4* d_tri_grp = nullptr; uint32_t* d_tri_perm = nullptr; uint32_t n_tri_groups = 0;
     u32x4* d_sph_gfrag = nullptr; float4* d_sph_grp = nullptr; uint32_t* d_sph_perm = nullptr; uint32_t n_sph_groups = 0;
+    float4* d_tri_leaf = nullptr; float4* d_sph_leaf = nullptr; uint32_t n_tri_leaves = 0, n_sph_leaves = 0;      // three-level filter: the leaf groups' bounds
     uint32_t* d_strips = nullptr; size_t strip_entries = 0;          // deferred member tests: kStripPairs pairs per wave of the grid
 
     // work buffers
@@ -301,7 +302,7 @@ uint32_t sphere_direct_list(const float* center_radius, uint32_t n, const float 
 // every ray anyway) and spheres whose record is not finite (no exact test can accept them) stay out.
 // Any order is correct — the nearest-hit key carries the sphere's own index, and the minimum over the keys does not depend on the order the
 // pairs are tested in — a compact one keeps the groups' bounding spheres small.
-void median_split_order(std::vector<uint32_t>& ids, const float* xyz_stride4, uint32_t group) {
+void median_split_order(std::vector<uint32_t>& ids, const float* xyz_stride4, uint32_t group, uint32_t super = 1) {
     struct Part { size_t begin, end; };
     std::vector<Part> stack;
     stack.push_back({ 0, ids.size() });
@@ -315,15 +316,18 @@ void median_split_order(std::vector<uint32_t>& ids, const float* xyz_stride4, ui
             for (int a = 0; a < 3; a++) { const float c = xyz_stride4[4 * (size_t)ids[k] + a]; lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
         int axis = 0;
         for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
-        size_t half = (count / 2 + group - 1) / group * group;
-        if (half >= count) half = count - group;                    // (count > group here)
+        // parts larger than a super group (group x super primitives: one row of the three-level filter) split at multiples of it, so that the
+        // `super` leaf groups of a row are one part of the split
+        const size_t unit = count > (size_t)group * super ? (size_t)group * super : group;
+        size_t half = (count / 2 + unit - 1) / unit * unit;
+        if (half >= count) half = count - unit;                     // (count > unit here)
         std::nth_element(ids.begin() + part.begin, ids.begin() + part.begin + half, ids.begin() + part.end,
                          [&](uint32_t x, uint32_t y) { return xyz_stride4[4 * (size_t)x + axis] < xyz_stride4[4 * (size_t)y + axis]; });
         stack.push_back({ part.begin + half, part.end });
         stack.push_back({ part.begin, part.begin + half });
     }
 }
-std::vector<uint32_t> sphere_group_order(const float* center_radius, uint32_t n, const uint32_t* direct, uint32_t n_direct, uint32_t group) {
+std::vector<uint32_t> sphere_group_order(const float* center_radius, uint32_t n, const uint32_t* direct, uint32_t n_direct, uint32_t group, uint32_t super) {
     std::vector<uint32_t> ids;
     ids.reserve(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -331,14 +335,14 @@ std::vector<uint32_t> sphere_group_order(const float* center_radius, uint32_t n,
         if (is_direct(i, direct, n_direct) || !std::isfinite(s[0]) || !std::isfinite(s[1]) || !std::isfinite(s[2]) || !std::isfinite(s[3] * s[3])) continue;
         ids.push_back(i);
     }
-    median_split_order(ids, center_radius, group);
-    ids.resize((ids.size() + group - 1) / group * group, 0xFFFFFFFFu);
+    median_split_order(ids, center_radius, group, super);
+    ids.resize((ids.size() + group * super - 1) / (group * super) * (group * super), 0xFFFFFFFFu);
     return ids;
 }
 // The same for faces, from their bounding spheres (cx, cy, cz, r^2 as k_commit_mesh wrote them): a mesh may list its faces in any order (the
 // reference's teddy.obj does), and groups of faces that merely follow each other in the file would span the model.  Faces without a bounded hit
 // region (r^2 >= 3e38: always candidates) go last, in groups of their own, so that they make only their own rows always-candidates.
-std::vector<uint32_t> face_group_order(const float4* bounds, uint32_t n, uint32_t group) {
+std::vector<uint32_t> face_group_order(const float4* bounds, uint32_t n, uint32_t group, uint32_t super) {
     std::vector<uint32_t> ids, unbounded;
     ids.reserve(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -346,10 +350,10 @@ std::vector<uint32_t> face_group_order(const float4* bounds, uint32_t n, uint32_
         if (std::isfinite(b.x) && std::isfinite(b.y) && std::isfinite(b.z) && b.w >= 0.0f && b.w < 3e38f) ids.push_back(i);
         else unbounded.push_back(i);
     }
-    median_split_order(ids, reinterpret_cast<const float*>(bounds), group);
-    ids.resize((ids.size() + group - 1) / group * group, 0xFFFFFFFFu);
+    median_split_order(ids, reinterpret_cast<const float*>(bounds), group, super);
+    ids.resize((ids.size() + group * super - 1) / (group * super) * (group * super), 0xFFFFFFFFu);
     ids.insert(ids.end(), unbounded.begin(), unbounded.end());
-    ids.resize((ids.size() + group - 1) / group * group, 0xFFFFFFFFu);
+    ids.resize((ids.size() + group * super - 1) / (group * super) * (group * super), 0xFFFFFFFFu);
     return ids;
 }
 
@@ -433,7 +437,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r,
-                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips, ctx->d_tri_grp, ctx->d_tri_perm };
+                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips, ctx->d_tri_grp, ctx->d_tri_perm, ctx->d_tri_leaf, ctx->d_sph_leaf };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -510,7 +514,7 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
     for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in,
-                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm })
+                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm, (void**)&ctx->d_tri_leaf })
         if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
     ctx->n_faces = 0; ctx->n_tri_groups = 0;
     if (n == 0) return 0;
@@ -564,16 +568,26 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     {
         std::vector<float4> bounds(n);
         RT3_HIP(hipMemcpy(bounds.data(), ctx->d_tri_bound, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-        const std::vector<uint32_t> order = face_group_order(bounds.data(), n, kGroupTri);
+        const std::vector<uint32_t> order = face_group_order(bounds.data(), n, kGroupTri, kSuper);
         std::vector<float4> grp(order.size(), kPadSphere);
         for (size_t k = 0; k < order.size(); k++) if (order[k] != 0xFFFFFFFFu) grp[k] = bounds[order[k]];
         int rc;
         if ((rc = upload(ctx, &ctx->d_tri_grp, grp)) || (rc = upload(ctx, &ctx->d_tri_perm, order))) return rc;
-        ctx->n_tri_groups = (uint32_t)(order.size() / kGroupTri);
+        ctx->n_tri_leaves = (uint32_t)(order.size() / kGroupTri);
+        ctx->n_tri_groups = ctx->n_tri_leaves / kSuper;                // rows the matrix filter scans
+        const float4* row_members = ctx->d_tri_grp;
+        uint32_t row_entries = (uint32_t)order.size(), row_group = kGroupTri;
+        if (kSuper > 1) {                                           // three levels: the leaves' bounds are records of their own, a row bounds kSuper of them
+            RT3_HIP(hipMalloc((void**)&ctx->d_tri_leaf, (size_t)ctx->n_tri_leaves * sizeof(float4)));
+            hipLaunchKernelGGL(k_group_bounds, dim3((ctx->n_tri_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_grp, (uint32_t)order.size(),
+                               kGroupTri, ctx->n_tri_leaves, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_leaf);
+            RT3_HIP(hipGetLastError());
+            row_members = ctx->d_tri_leaf; row_entries = ctx->n_tri_leaves; row_group = kSuper;
+        }
         const uint32_t n_group_rows = (ctx->n_tri_groups + 31u) / 32u * 32u;
         RT3_HIP(hipMalloc((void**)&ctx->d_tri_gfrag, (size_t)n_group_rows * 4 * sizeof(u32x4)));
-        hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_grp, (uint32_t)order.size(),
-                           kGroupTri, n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_gfrag);
+        hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_members, row_entries,
+                           row_group, n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_gfrag);
         RT3_HIP(hipGetLastError());
         RT3_HIP(hipStreamSynchronize(ctx->stream));                 // a render may come on another stream
     }
@@ -626,18 +640,28 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
         return rc;
     // rows of the two-level filter: groups of kGroupSph spheres in the order of a spatial median split
     {
-        const std::vector<uint32_t> order = sphere_group_order(center_radius, n, ctx->direct, ctx->n_direct, kGroupSph);
+        const std::vector<uint32_t> order = sphere_group_order(center_radius, n, ctx->direct, ctx->n_direct, kGroupSph, kSuper);
         std::vector<float4> grp(order.size(), kPadSphere);
         for (size_t k = 0; k < order.size(); k++) if (order[k] != 0xFFFFFFFFu) grp[k] = sph[order[k]];
         if ((rc = upload(ctx, &ctx->d_sph_grp, grp)) || (rc = upload(ctx, &ctx->d_sph_perm, order))) return rc;
-        if (ctx->d_sph_gfrag) { RT3_HIP(hipFree(ctx->d_sph_gfrag)); ctx->d_sph_gfrag = nullptr; }
-        ctx->n_sph_groups = (uint32_t)(order.size() / kGroupSph);
+        for (void** b : { (void**)&ctx->d_sph_gfrag, (void**)&ctx->d_sph_leaf }) if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
+        ctx->n_sph_leaves = (uint32_t)(order.size() / kGroupSph);
+        ctx->n_sph_groups = ctx->n_sph_leaves / kSuper;                // rows the matrix filter scans
         if (ctx->n_sph_groups) {
+            const float4* row_members = ctx->d_sph_grp;
+            uint32_t row_entries = (uint32_t)order.size(), row_group = kGroupSph;
+            if (kSuper > 1) {
+                RT3_HIP(hipMalloc((void**)&ctx->d_sph_leaf, (size_t)ctx->n_sph_leaves * sizeof(float4)));
+                hipLaunchKernelGGL(k_group_bounds, dim3((ctx->n_sph_leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_sph_grp,
+                                   (uint32_t)order.size(), kGroupSph, ctx->n_sph_leaves, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2],
+                                   ctx->d_sph_leaf);
+                RT3_HIP(hipGetLastError());
+                row_members = ctx->d_sph_leaf; row_entries = ctx->n_sph_leaves; row_group = kSuper;
+            }
             const uint32_t n_group_rows = (ctx->n_sph_groups + 31u) / 32u * 32u;
             RT3_HIP(hipMalloc((void**)&ctx->d_sph_gfrag, (size_t)n_group_rows * 4 * sizeof(u32x4)));
-            hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_sph_grp,
-                               (uint32_t)order.size(), kGroupSph, n_group_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2],
-                               ctx->d_sph_gfrag);
+            hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_members, row_entries, row_group,
+                               n_group_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2], ctx->d_sph_gfrag);
             RT3_HIP(hipGetLastError());
             RT3_HIP(hipStreamSynchronize(ctx->stream));             // a render may come on another stream
         }
@@ -846,6 +870,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     A.n_tri_rows = grouped ? ctx->n_tri_groups : ctx->n_faces;
     A.n_sph_rows = grouped ? ctx->n_sph_groups : ctx->n_sph;
     A.sph_grp = ctx->d_sph_grp; A.sph_perm = ctx->d_sph_perm; A.tri_grp = ctx->d_tri_grp; A.tri_perm = ctx->d_tri_perm;
+    A.tri_leaf = ctx->d_tri_leaf; A.sph_leaf = ctx->d_sph_leaf; A.n_tri_leaves = ctx->n_tri_leaves; A.n_sph_leaves = ctx->n_sph_leaves;
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
     TraceKernel plain = nullptr;
     TiledKernel tiled = nullptr;
@@ -863,10 +888,10 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         kptr = single_k64 ? (const void*)k_trace_mfma : (const void*)k_trace_mfma32;
     } else if (use_mfma) {
         // the two-level filter (rows = groups of primitives) unless RT3_NO_GROUPS=1 asks for the flat one (A/B reference, tests)
-        constexpr uint32_t GT = kGroupTri, GS = kGroupSph;
+        constexpr uint32_t GT = kGroupTri, GS = kGroupSph, SUP = kSuper;
         if (grouped)
-            tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false, GT, GS> : (ref ? k_trace_mfma_tiled<true, false, true, GT, 1> : k_trace_mfma_tiled<true, false, false, GT, 1>))
-                            : k_trace_mfma_tiled<false, true, false, 1, GS>;
+            tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false, GT, GS, SUP> : (ref ? k_trace_mfma_tiled<true, false, true, GT, 1, SUP> : k_trace_mfma_tiled<true, false, false, GT, 1, SUP>))
+                            : k_trace_mfma_tiled<false, true, false, 1, GS, SUP>;
         else
             tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
                             : k_trace_mfma_tiled<false, true, false>;

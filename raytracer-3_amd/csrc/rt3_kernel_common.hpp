@@ -135,6 +135,9 @@ struct TraceArgs {
     // records — the spheres themselves, the faces' bounding spheres — in GROUP order (row g = entries [g G, (g + 1) G)), *_perm the primitive
     // index of each (0xFFFFFFFF: padding; the direct spheres are in no group).  *_rows: rows the pass scans (= primitives when G is 1).
     const float4* sph_grp; const uint32_t* sph_perm; const float4* tri_grp; const uint32_t* tri_perm; uint32_t n_sph_rows, n_tri_rows;
+    // Three levels (kSuper > 1): a row bounds kSuper consecutive LEAF groups; *_leaf holds the leaves' bounding spheres (cx, cy, cz, R_eff^2), which a
+    // candidate row's rays are tested against in f32 before the leaves' members are.  n_*_leaves: leaf groups (= rows x kSuper).
+    const float4* sph_leaf; const float4* tri_leaf; uint32_t n_sph_leaves, n_tri_leaves;
     uint32_t* pair_strips;   // [wave of the grid][kStripPairs]: candidate (ray lane, row) pairs set aside for the end of a pass (deferred member tests)
     uint32_t* work_counter;
     unsigned long long* cast_counter;

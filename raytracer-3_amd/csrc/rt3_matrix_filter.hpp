@@ -840,13 +840,13 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma32(const TraceArgs A, const u
 #define RT3_TILE_LOADS 4
 #endif
 #ifndef RT3_BM_BLOCKS
-#define RT3_BM_BLOCKS 16
+#define RT3_BM_BLOCKS 12
 #endif
 constexpr uint32_t kTB = RT3_TILED_TB;                              // threads per workgroup of k_trace_mfma_tiled
 constexpr uint32_t kTileLoads = RT3_TILE_LOADS;                     // 16-byte vectors per thread and tile: the fragment tile is kTB * kTileLoads * 16 bytes
 constexpr uint32_t kBmBlocks = RT3_BM_BLOCKS;                       // row blocks scanned before their candidate words are pushed (words: kBmBlocks * kTB * 4 bytes)
 constexpr size_t kTiledLdsBytes = (size_t)16 * 4096 + kBitmapBytes + (size_t)kMB * 8 + (size_t)(kMB / 64) * kPairCap * 4;     // k_mode_r_mfma
-constexpr size_t kTraceTiledLdsBytes = (size_t)kTB * (kTileLoads * 16 + kBmBlocks * 4 + 8) + (size_t)(kTB / 64) * kPairCap * 4 * 2;      // two pair lists per wave
+constexpr size_t kTraceTiledLdsBytes = (size_t)kTB * (kTileLoads * 16 + kBmBlocks * 4 + 8) + (size_t)(kTB / 64) * kPairCap * 4 * 3;      // three pair lists per wave: 160 KiB in all
 // One tile of fragments through the workgroup: [barrier] loads -> LDS stores [barrier].
 template <uint32_t TB = kMB, uint32_t LOADS = 4>
 __device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict__ src, uint32_t n_vec, uint32_t tid) {
@@ -868,8 +868,14 @@ __device__ __forceinline__ void fill_tile(u32x4* s_frag, const u32x4* __restrict
 #ifndef RT3_GROUP_SPH
 #define RT3_GROUP_SPH 8
 #endif
-constexpr uint32_t kGroupTri = RT3_GROUP_TRI, kGroupSph = RT3_GROUP_SPH;
-template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t GT = 1, uint32_t GS = 1>
+#ifndef RT3_SUPER
+#define RT3_SUPER 8                                                 // leaf groups per row of the matrix filter (1: two levels, rows = leaf groups)
+#endif
+constexpr uint32_t kGroupTri = RT3_GROUP_TRI, kGroupSph = RT3_GROUP_SPH, kSuper = RT3_SUPER;
+// SUP > 1 (with GT, GS > 1): three levels — a row bounds SUP consecutive leaf groups; a candidate row's ray is first tested, in f32, against the SUP
+// leaves' bounding spheres (A.*_leaf; scan_tile's arithmetic with a margin of 1e-4 c, which covers what the exact sphere test's own rounding lets
+// through: DESIGN.md 5.2e), the surviving (ray lane, leaf) pairs go through a list of their own to the members' tests described above.
+template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t GT = 1, uint32_t GS = 1, uint32_t SUP = 1>
 __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     static_assert(64 % GT == 0 && 64 % GS == 0, "group sizes must divide the wave");
     extern __shared__ u32x4 lds_dyn[];
@@ -878,8 +884,9 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
     unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + kBmBlocks * kTB);   // [kTB] nearest hit of every lane's ray
     uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kTB);              // [waves][2][kPairCap]
     const uint32_t tid = threadIdx.x, lane = lane_id();
-    uint32_t* pairs = s_pairs + (tid / 64u) * (2 * kPairCap);                  // (ray lane, row) pairs from the scan
+    uint32_t* pairs = s_pairs + (tid / 64u) * (3 * kPairCap);                  // (ray lane, row) pairs from the scan
     uint32_t* fpairs = pairs + kPairCap;                                       // GT > 1: (ray lane, face) pairs that passed their own bound
+    uint32_t* lpairs = fpairs + kPairCap;                                      // SUP > 1: (ray lane, leaf group) pairs that passed the leaf's bound
     unsigned long long* keys = s_key + (tid & ~63u);                           // this wave's 64 records
     uint32_t* strip = A.pair_strips + ((size_t)blockIdx.x * (kTB / 64u) + tid / 64u) * kStripPairs;     // deferred member tests (GT, GS > 1)
 
@@ -915,7 +922,52 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
 #endif
         if (HAS_SPH && !HAS_TRI) build_ray_operands32(ray.ox - A.fcx, ray.oy - A.fcy, ray.oz - A.fcz, ux, uy, uz, alive, R32);
         keys[lane] = HAS_SPH ? direct_tests(A, ray.ox, ray.oy, ray.oz, ray.dx, ray.dy, ray.dz, [&](uint32_t j) { return A.sph[j]; }) : kKeyNone;
-        uint32_t n_pairs = 0, n_fpairs = 0, n_strip = 0;
+        uint32_t n_pairs = 0, n_fpairs = 0, n_lpairs = 0, n_strip = 0;
+        // SUP > 1: the middle level.  A batch of (ray lane, row) pairs, LPP lanes per pair, each lane SUP / LPP leaf bounds (its own contiguous bytes);
+        // survivors are appended to lpairs and handed, 64 / LPP at a time, to `leaf_fn` (the members' tests of the two-level filter).
+        auto super_stage = [&](const float4* __restrict__ leaf_bounds, uint32_t n_rows, auto lpp_tag, auto&& leaf_fn) {
+            return [&, leaf_bounds, n_rows](uint32_t pair, bool valid, uint32_t part) {
+                constexpr uint32_t LPPL = decltype(lpp_tag)::value;                 // lanes per pair of the LEAF stage: its batches take 64 / LPPL pairs
+                constexpr uint32_t LPPS = kLanesPerPair < SUP ? kLanesPerPair : SUP, MPLS = SUP / LPPS;
+                const uint32_t src = pair >> kPairLaneShift, g = pair & ((1u << kPairLaneShift) - 1u);
+                const int sl = (int)src;
+                const float sox = __shfl(ray.ox, sl), soy = __shfl(ray.oy, sl), soz = __shfl(ray.oz, sl);
+                const float sdx = __shfl(ux, sl), sdy = __shfl(uy, sl), sdz = __shfl(uz, sl);
+                bound_tests += (unsigned long long)__popcll(__ballot(valid)) * MPLS;
+                const bool ok = valid && g < n_rows;
+                const uint32_t l0 = ok ? g * SUP + part * MPLS : 0u;
+                float4 b[MPLS];
+#pragma unroll
+                for (uint32_t m = 0; m < MPLS; m++) b[m] = leaf_bounds[l0 + m];
+#pragma unroll
+                for (uint32_t m = 0; m < MPLS; m++) {
+                    const float cx = b[m].x - sox, cy = b[m].y - soy, cz = b[m].z - soz;
+                    const float h = fma_(cz, sdz, fma_(cy, sdy, cx * sdx));
+                    const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -b[m].w)));
+                    const float disc = fma_(1e-4f, c, fma_(h, h, -c));
+                    const bool keep = ok && ((__float_as_uint(disc) >> 31) == 0u || b[m].w >= 3e38f);   // (a leaf with an unbounded member: always)
+                    const unsigned long long km = __ballot(keep);
+                    if (km == 0ull) continue;
+                    if (keep) lpairs[n_lpairs + prefix_count(km)] = (src << kPairLaneShift) | (l0 + m);
+                    n_lpairs += (uint32_t)__popcll(km);
+                    __builtin_amdgcn_wave_barrier();
+                    while (n_lpairs >= 64u / LPPL) {
+                        n_lpairs -= 64u / LPPL;
+                        leaf_fn(lpairs[n_lpairs + lane / LPPL], true, lane % LPPL);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            };
+        };
+        auto flush_leaves = [&](auto lpp_tag, auto&& leaf_fn) {                    // what is left in lpairs at the end of a pass
+            constexpr uint32_t LPPL = decltype(lpp_tag)::value;
+            if (n_lpairs != 0u) {
+                const bool valid = lane / LPPL < n_lpairs;
+                leaf_fn(valid ? lpairs[lane / LPPL] : 0u, valid, lane % LPPL);
+                __builtin_amdgcn_wave_barrier();
+                n_lpairs = 0u;
+            }
+        };
 
         auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto group_tag, auto&& test, auto&& finish) {
             constexpr bool K32 = decltype(k32)::value;                          // spheres: 2 operand fragments (2 KiB) per row block, else 4
@@ -977,7 +1029,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     const float sox = __shfl(ray.ox, sl), soy = __shfl(ray.oy, sl), soz = __shfl(ray.oz, sl);
                     const float sdx = __shfl(ux, sl), sdy = __shfl(uy, sl), sdz = __shfl(uz, sl);
                     bound_tests += (unsigned long long)__popcll(__ballot(valid)) * MPL;
-                    const uint32_t p0 = valid && g < A.n_tri_rows ? g * GT + part * MPL : 0u;
+                    const uint32_t p0 = valid && g < A.n_tri_leaves ? g * GT + part * MPL : 0u;
                     float4 b[MPL];                                                  // this lane's members' bounds (group order): MPL x 16 contiguous bytes
 #pragma unroll
                     for (uint32_t m = 0; m < MPL; m++) b[m] = A.tri_grp[p0 + m];
@@ -989,7 +1041,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                         const float disc = fma_(1e-5f, c, fma_(h, h, -c));
                         // the sign bit, as scan_tile reads it (padding: r^2 = -1e30); a face without a bounded hit region (r^2 = 3e38, possibly a
                         // non-finite centre) goes to the exact test whatever the arithmetic above made of it
-                        const bool keep = valid && g < A.n_tri_rows && ((__float_as_uint(disc) >> 31) == 0u || b[m].w >= 3e38f);
+                        const bool keep = valid && g < A.n_tri_leaves && ((__float_as_uint(disc) >> 31) == 0u || b[m].w >= 3e38f);
                         const unsigned long long km = __ballot(keep);
                         if (km == 0ull) continue;
                         if (keep) fpairs[n_fpairs + prefix_count(km)] = (src << kPairLaneShift) | A.tri_perm[p0 + m];
@@ -1002,13 +1054,25 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                         }
                     }
                 };
-                pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, GT>(), face_group,
-                     [&]() {
-                         if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
-                         drain_strip<LPP>(lane, strip, n_strip + n_pairs, face_group);
-                         n_strip = 0u; n_pairs = 0u;
-                         test_all(lane, fpairs, n_fpairs, face_test);
-                     });
+                if constexpr (SUP == 1) {
+                    pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, GT>(), face_group,
+                         [&]() {
+                             if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                             drain_strip<LPP>(lane, strip, n_strip + n_pairs, face_group);
+                             n_strip = 0u; n_pairs = 0u;
+                             test_all(lane, fpairs, n_fpairs, face_test);
+                         });
+                } else {
+                    auto stage = super_stage(A.tri_leaf, A.n_tri_rows, std::integral_constant<uint32_t, LPP>(), face_group);
+                    pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
+                         [&]() {
+                             if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                             drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip + n_pairs, stage);
+                             n_strip = 0u; n_pairs = 0u;
+                             flush_leaves(std::integral_constant<uint32_t, LPP>(), face_group);
+                             test_all(lane, fpairs, n_fpairs, face_test);
+                         });
+                }
             }
         }
         if (HAS_SPH) {
@@ -1030,7 +1094,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     const uint32_t src = pair >> kPairLaneShift, g = pair & ((1u << kPairLaneShift) - 1u);
                     const LaneRay r = fetch_ray<false>(ray, src);
                     exact += (unsigned long long)__popcll(__ballot(valid)) * MPL;
-                    const bool ok = valid && g < A.n_sph_rows;
+                    const bool ok = valid && g < A.n_sph_leaves;
                     const uint32_t p0 = ok ? g * GS + part * MPL : 0u;
                     float4 sm[MPL];                                                 // this lane's members' records (group order): MPL x 16 contiguous bytes
 #pragma unroll
@@ -1042,12 +1106,23 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                             atomicMin(&keys[src], hit_key(t, 1u, A.sph_perm[p0 + m]));
                     }
                 };
-                pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, GS>(), sphere_group,
-                     [&]() {
-                         if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
-                         drain_strip<LPP>(lane, strip, n_strip + n_pairs, sphere_group);
-                         n_strip = 0u; n_pairs = 0u;
-                     });
+                if constexpr (SUP == 1) {
+                    pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, GS>(), sphere_group,
+                         [&]() {
+                             if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                             drain_strip<LPP>(lane, strip, n_strip + n_pairs, sphere_group);
+                             n_strip = 0u; n_pairs = 0u;
+                         });
+                } else {
+                    auto stage = super_stage(A.sph_leaf, A.n_sph_rows, std::integral_constant<uint32_t, LPP>(), sphere_group);
+                    pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
+                         [&]() {
+                             if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                             drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip + n_pairs, stage);
+                             n_strip = 0u; n_pairs = 0u;
+                             flush_leaves(std::integral_constant<uint32_t, LPP>(), sphere_group);
+                         });
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();

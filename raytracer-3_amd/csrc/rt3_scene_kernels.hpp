@@ -200,57 +200,80 @@ __global__ void k_commit_mesh(const rt3_gface* __restrict__ faces, const float4*
 //   the face's bound — its inflation is 80x the rounding of a hit point — so for faces the same inflation is pure slack.)
 // A member with r^2 >= 3e38 (a face without a bounded hit region) makes its row an always-candidate; members with a negative or non-finite
 // record (padding; spheres no exact test can ever accept) do not count; a row without members can never be a candidate.
+// The bounding sphere of group g: (C', R_eff^2) with C' in WORLD coordinates, or r^2 = 3e38 (always a candidate) / -1e30 (never: no usable member).
+__device__ __forceinline__ float4 group_bound(const float4* __restrict__ bounds, uint32_t n_entries, uint32_t group, uint32_t g, const float centre[3]) {
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    uint32_t members = 0;
+    bool always = false;
+    auto usable = [](const float4& b) { return b.w >= 0.0f && b.w < 3e38f && b.x - b.x == 0.0f && b.y - b.y == 0.0f && b.z - b.z == 0.0f; };
+    for (uint32_t m = 0; m < group; m++) {
+        const uint64_t j = (uint64_t)g * group + m;
+        if (j >= n_entries) break;
+        const float4 b = bounds[j];
+        if (b.w >= 3e38f) { always = true; continue; }              // (whatever its centre is)
+        if (!usable(b)) continue;
+        sx += b.x; sy += b.y; sz += b.z; members++;
+    }
+    if (always) return make_float4(0.0f, 0.0f, 0.0f, 3e38f);
+    if (members == 0) return kPadSphere;
+    // centre: towards the smallest enclosing sphere of the members' spheres (Badoiu-Clarkson: start at the mean, step 1 / (k + 1) towards the
+    // farthest member, 32 times) — R^2 comes out a quarter smaller than about the mean on the 100 000-sphere scene, and with it the candidates;
+    // any centre is correct, R below is measured from whichever one this ends on
+    double cx = sx / members, cy = sy / members, cz = sz / members;
+    for (int it = 1; it <= 32 && members > 1; it++) {
+        double far = -1.0, tx = cx, ty = cy, tz = cz;
+        for (uint32_t m = 0; m < group; m++) {
+            const uint64_t j = (uint64_t)g * group + m;
+            if (j >= n_entries) break;
+            const float4 b = bounds[j];
+            if (!usable(b)) continue;
+            const double ddx = b.x - cx, ddy = b.y - cy, ddz = b.z - cz, d = sqrt(ddx * ddx + ddy * ddy + ddz * ddz) + sqrt((double)b.w);
+            if (d > far) { far = d; tx = b.x; ty = b.y; tz = b.z; }
+        }
+        const double step = 1.0 / (it + 1);
+        cx += (tx - cx) * step; cy += (ty - cy) * step; cz += (tz - cz) * step;
+    }
+    const float fcx = (float)cx, fcy = (float)cy, fcz = (float)cz;  // the centre as it is stored: R is measured from THIS point
+    double R = 0.0;
+    for (uint32_t m = 0; m < group; m++) {
+        const uint64_t j = (uint64_t)g * group + m;
+        if (j >= n_entries) break;
+        const float4 b = bounds[j];
+        if (!usable(b)) continue;
+        const double ddx = (double)b.x - fcx, ddy = (double)b.y - fcy, ddz = (double)b.z - fcz;
+        R = fmax(R, sqrt(ddx * ddx + ddy * ddy + ddz * ddz) + sqrt((double)b.w));
+    }
+    const double qx = (double)fcx - centre[0], qy = (double)fcy - centre[1], qz = (double)fcz - centre[2];
+    const double rho = sqrt(qx * qx + qy * qy + qz * qz) + R;
+    const double r2 = (1.04 * R * R + 2e-3 * R * rho + 4e-6 * rho * rho) * (1.0 + 1e-6) + 1e-30;
+    if (!(r2 < 1e30)) return make_float4(0.0f, 0.0f, 0.0f, 3e38f);
+    float r2f = (float)r2;
+    if ((double)r2f < r2) r2f = __uint_as_float(__float_as_uint(r2f) + 1u);
+    return make_float4(fcx, fcy, fcz, r2f);
+}
+// The groups' bounds as records (three-level filter: the leaves' spheres, which the middle level tests in f32).
+__global__ void k_group_bounds(const float4* __restrict__ bounds, uint32_t n_entries, uint32_t group, uint32_t n_groups, const uint32_t* __restrict__ box,
+                               float ecx, float ecy, float ecz, float4* __restrict__ out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    float centre[3] = { ecx, ecy, ecz };
+    if (box) box_centre(box, centre);
+    out[g] = group_bound(bounds, n_entries, group, g, centre);
+}
+// The groups' bounds as rows of the matrix filter (K = 32 fragments about the filter's centre).
 __global__ void k_group_frags(const float4* __restrict__ bounds, uint32_t n_entries, uint32_t group, uint32_t n_rows_padded,
                               const uint32_t* __restrict__ box, float ecx, float ecy, float ecz, u32x4* __restrict__ frag) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_rows_padded) return;
     float centre[3] = { ecx, ecy, ecz };
     if (box) box_centre(box, centre);
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    uint32_t members = 0;
-    bool always = false;
-    for (uint32_t m = 0; m < group; m++) {
-        const uint64_t j = (uint64_t)g * group + m;
-        if (j >= n_entries) break;
-        const float4 b = bounds[j];
-        if (b.w >= 3e38f) { always = true; continue; }              // (whatever its centre is)
-        if (!(b.w >= 0.0f) || !(b.x - b.x == 0.0f) || !(b.y - b.y == 0.0f) || !(b.z - b.z == 0.0f)) continue;
-        sx += b.x; sy += b.y; sz += b.z; members++;
-    }
+    const float4 gb = group_bound(bounds, n_entries, group, g, centre);
     float fx = 0.0f, fy = 0.0f, fz = 0.0f, kj = kNeverCandidate;
-    if (always) kj = kAlwaysCandidate;
-    else if (members != 0) {
-        // centre: towards the smallest enclosing sphere of the members' spheres (Badoiu-Clarkson: start at the mean, step 1 / (k + 1) towards the
-        // farthest member, 32 times) — R^2 comes out a quarter smaller than about the mean on the 100 000-sphere scene, and with it the candidates;
-        // any centre is correct, R below is measured from whichever one this ends on
-        double cx = sx / members, cy = sy / members, cz = sz / members;
-        auto usable = [](const float4& b) { return b.w >= 0.0f && b.w < 3e38f && b.x - b.x == 0.0f && b.y - b.y == 0.0f && b.z - b.z == 0.0f; };
-        for (int it = 1; it <= 32 && members > 1; it++) {
-            double far = -1.0, tx = cx, ty = cy, tz = cz;
-            for (uint32_t m = 0; m < group; m++) {
-                const uint64_t j = (uint64_t)g * group + m;
-                if (j >= n_entries) break;
-                const float4 b = bounds[j];
-                if (!usable(b)) continue;
-                const double ddx = b.x - cx, ddy = b.y - cy, ddz = b.z - cz, d = sqrt(ddx * ddx + ddy * ddy + ddz * ddz) + sqrt((double)b.w);
-                if (d > far) { far = d; tx = b.x; ty = b.y; tz = b.z; }
-            }
-            const double step = 1.0 / (it + 1);
-            cx += (tx - cx) * step; cy += (ty - cy) * step; cz += (tz - cz) * step;
-        }
-        double R = 0.0;
-        for (uint32_t m = 0; m < group; m++) {
-            const uint64_t j = (uint64_t)g * group + m;
-            if (j >= n_entries) break;
-            const float4 b = bounds[j];
-            if (!usable(b)) continue;
-            const double ddx = b.x - cx, ddy = b.y - cy, ddz = b.z - cz;
-            R = fmax(R, sqrt(ddx * ddx + ddy * ddy + ddz * ddz) + sqrt((double)b.w));
-        }
-        fx = (float)(cx - (double)centre[0]); fy = (float)(cy - (double)centre[1]); fz = (float)(cz - (double)centre[2]);
-        const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz, rho = sqrt(c2) + R;
-        const double r2 = (1.04 * R * R + 2e-3 * R * rho + 4e-6 * rho * rho) * (1.0 + 1e-6) + 1e-30;
-        kj = r2 < 1e30 ? filter_kj32(c2, r2) : kAlwaysCandidate;
+    if (gb.w >= 3e38f) kj = kAlwaysCandidate;
+    else if (gb.w >= 0.0f) {
+        fx = (float)((double)gb.x - (double)centre[0]); fy = (float)((double)gb.y - (double)centre[1]); fz = (float)((double)gb.z - (double)centre[2]);
+        const double c2 = (double)fx * fx + (double)fy * fy + (double)fz * fz;
+        kj = filter_kj32(c2, (double)gb.w);
     }
     uint32_t fr[4][4];
     bound_frag32_row(fx, fy, fz, kj, fr);
