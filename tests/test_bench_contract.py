@@ -144,6 +144,6 @@ def test_full_workload_line_carries_the_binding_unit_and_the_extra_workloads(tmp
     for name in ("config 4", "config 5"):
         w = ew[name]
         f = w["filter"]
-        assert f["levels"] == 2 and f["filter_tests_executed"] * 7 < w["prim_tests"] and w["tests_per_s"] > 3e13       # brute-force equivalent
+        assert f["levels"] == 3 and f["filter_tests_executed"] * 50 < w["prim_tests"] and w["tests_per_s"] > 5e13       # brute-force equivalent
         assert "valu_issue" in w and "mfma_busy" in w and "counters_source" in w
-    assert ew["config 5"]["filter"]["member_bound_tests_per_cast"] > 0 and ew["config 4"]["exact_tests_per_cast"] > 100
+    assert ew["config 5"]["filter"]["bound_tests_per_cast"] > 0 and ew["config 4"]["exact_tests_per_cast"] > 100

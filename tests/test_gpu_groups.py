@@ -1,7 +1,7 @@
-"""The two-level candidate filter of k_trace_mfma_tiled: a row of the matrix filter is the bounding sphere of a GROUP of
-primitives (faces in face order, spheres in the order of a spatial median split), a candidate row expands into member tests.  It only has to be
-conservative — the exact tests and the (t, kind, index) key are those of the flat filter — so every frame must equal the flat filter's, the
-unfiltered kernel's and the oracle's bit for bit, while the matrix filter evaluates 1 / GROUP of the (ray, row) pairs."""
+"""The multi-level candidate filter of k_trace_mfma_tiled: a row of the matrix filter is the bounding sphere of 8 LEAF groups of 8
+primitives each (grouped by a spatial median split); a candidate row's ray is tested in f32 against the 8 leaves' bounds, a surviving leaf expands into
+member tests.  It only has to be conservative — the exact tests and the (t, kind, index) key are those of the flat filter — so every frame must equal
+the flat filter's, the unfiltered kernel's and the oracle's bit for bit, while the matrix filter evaluates 1 / 64 of the (ray, row) pairs."""
 import numpy as np
 import pytest
 
@@ -44,13 +44,12 @@ def test_grouped_filter_equals_flat_filter_equals_brute_on_random_soups(rt3, ren
         case.update(spheres=cr, smats=sm)
     grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
     assert np.array_equal(flat, brute), "flat filter != brute"
-    assert np.array_equal(grouped, brute), "two-level filter != brute: %d pixels" % int((grouped != brute).sum())
+    assert np.array_equal(grouped, brute), "multi-level filter != brute: %d pixels" % int((grouped != brute).sum())
     assert st_g.ray_casts == st_f.ray_casts
     assert st_f.filter_tests == st_f.prim_tests                           # flat: one row per primitive
     rows_g, rows_f = st_g.filter_tests // st_g.ray_casts, st_f.filter_tests // st_f.ray_casts
-    assert rows_g <= rows_f // 8 + 2 and st_g.mfma_instructions < st_f.mfma_instructions
-    if n_faces:
-        assert st_g.bound_tests > 0 and st_f.bound_tests == 0
+    assert rows_g <= rows_f // 64 + 3 and st_g.mfma_instructions < st_f.mfma_instructions
+    assert st_g.bound_tests > 0 and st_f.bound_tests == 0          # the leaves' (and the faces' own) bounds, tested in f32
     want, casts = oracle_render(case, threads=16)
     assert np.array_equal(grouped, want) and casts == st_g.ray_casts
 
@@ -63,14 +62,14 @@ def test_coherent_scenes_test_fewer_members_than_the_flat_filter_tests_rows(rt3,
     case = dict(faces=f, verts=v, fmats=m, cam=cam.c, params=dict(width=128, height=128, spp=4, max_depth=8, seed=4, flags=1 | 2))
     grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
     assert np.array_equal(grouped, flat) and np.array_equal(flat, brute)
-    assert st_g.filter_tests * 7 < st_f.filter_tests
+    assert st_g.filter_tests * 50 < st_f.filter_tests
     assert st_g.exact_tests < 2 * st_f.exact_tests and st_g.bound_tests < st_f.filter_tests // 4
     cr, mats = rt3.scene_stress(6000, 7)
     cam = rt3.Camera().look_at(160, 90, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
     case = dict(spheres=cr, smats=mats, cam=cam.c, params=dict(width=160, height=90, spp=4, max_depth=8, seed=2, flags=1))
     grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
     assert np.array_equal(grouped, flat) and np.array_equal(flat, brute)
-    assert st_g.filter_tests * 7 < st_f.filter_tests and st_g.exact_tests < st_f.filter_tests // 8
+    assert st_g.filter_tests * 50 < st_f.filter_tests and st_g.exact_tests < st_f.filter_tests // 8
 
 
 def test_spheres_no_exact_test_can_accept_and_direct_spheres_stay_out_of_the_groups(rt3, renderer):
