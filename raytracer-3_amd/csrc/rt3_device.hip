@@ -874,6 +874,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
     TraceKernel plain = nullptr;
     TiledKernel tiled = nullptr;
+    bool resident = false;
     size_t lds = 0;
     int block = kBlock;
     const void* kptr = nullptr;
@@ -889,15 +890,21 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     } else if (use_mfma) {
         // the two-level filter (rows = groups of primitives) unless RT3_NO_GROUPS=1 asks for the flat one (A/B reference, tests)
         constexpr uint32_t GT = kGroupTri, GS = kGroupSph, SUP = kSuper;
-        if (grouped)
+        const uint32_t row_blocks = (has_tri ? (A.n_tri_rows + 31u) / 32u : 0u) + (has_sph ? (A.n_sph_rows + 31u) / 32u : 0u);
+        resident = grouped && SUP > 1 && row_blocks <= kResidentBlocks && !getenv("RT3_NO_RESIDENT");      // all rows fit in LDS: no tiles, no barriers
+        if (resident)
+            tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false, GT, GS, SUP, true> : (ref ? k_trace_mfma_tiled<true, false, true, GT, 1, SUP, true> : k_trace_mfma_tiled<true, false, false, GT, 1, SUP, true>))
+                            : k_trace_mfma_tiled<false, true, false, 1, GS, SUP, true>;
+        else if (grouped)
             tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false, GT, GS, SUP> : (ref ? k_trace_mfma_tiled<true, false, true, GT, 1, SUP> : k_trace_mfma_tiled<true, false, false, GT, 1, SUP>))
                             : k_trace_mfma_tiled<false, true, false, 1, GS, SUP>;
         else
             tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
                             : k_trace_mfma_tiled<false, true, false>;
-        lds = kTraceTiledLdsBytes;
+        lds = resident ? (size_t)row_blocks * 2048u + (size_t)kBmBlocksRes * kTB * 4u + (size_t)kTB * 8u + (size_t)(kTB / 64u) * kPairCap * 4u * 3u : kTraceTiledLdsBytes;
         block = kTB;
         kptr = (const void*)tiled;
+
     } else {
         lds = sph_lds ? (size_t)ctx->n_sph * sizeof(float4) : 0;
         plain = has_tri ? (has_sph ? (sph_lds ? k_trace<true, true, true> : k_trace<true, true, false>)

@@ -875,13 +875,21 @@ constexpr uint32_t kGroupTri = RT3_GROUP_TRI, kGroupSph = RT3_GROUP_SPH, kSuper 
 // SUP > 1 (with GT, GS > 1): three levels — a row bounds SUP consecutive leaf groups; a candidate row's ray is first tested, in f32, against the SUP
 // leaves' bounding spheres (A.*_leaf; scan_tile's arithmetic with a margin of 1e-4 c, which covers what the exact sphere test's own rounding lets
 // through: DESIGN.md 5.2e), the surviving (ray lane, leaf) pairs go through a list of their own to the members' tests described above.
-template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t GT = 1, uint32_t GS = 1, uint32_t SUP = 1>
+// RES (with three levels): ALL rows of the scene stay in LDS — 64 B per row of 64 primitives: 100 KiB for the 100 000-sphere scene — loaded once; no tile
+// fill and no barrier after the prologue, the 16 waves of the workgroup run free as k_trace_mfma32's do (each leaves when its own paths are done).
+// The host picks it when the rows fit (kResidentBlocks); the candidate words then cover kBmBlocksRes row blocks per push.
+constexpr uint32_t kBmBlocksRes = 4;
+constexpr uint32_t kResidentBlocks = (160u * 1024u - kTB * 8u - (kTB / 64u) * kPairCap * 4u * 3u - kBmBlocksRes * kTB * 4u) / 2048u;      // row blocks of 2 KiB: 56
+template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t GT = 1, uint32_t GS = 1, uint32_t SUP = 1, bool RES = false>
 __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     static_assert(64 % GT == 0 && 64 % GS == 0, "group sizes must divide the wave");
+    static_assert(!RES || (SUP > 1 && RT3_FACE_K32), "resident rows: three-level filter only");
+    constexpr uint32_t BM = RES ? kBmBlocksRes : kBmBlocks;                     // row blocks per push
     extern __shared__ u32x4 lds_dyn[];
-    u32x4* s_frag = lds_dyn;                                                   // kTB * kTileLoads vectors: [16][4][64] at 1024 threads x 4
-    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + kTB * kTileLoads);   // [kBmBlocks][kTB] candidate words
-    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + kBmBlocks * kTB);   // [kTB] nearest hit of every lane's ray
+    const uint32_t res_tri_blocks = HAS_TRI ? (A.n_tri_rows + 31u) / 32u : 0u, res_sph_blocks = HAS_SPH ? (A.n_sph_rows + 31u) / 32u : 0u;
+    u32x4* s_frag = lds_dyn;                                                   // tiles: kTB * kTileLoads vectors ([16][4][64] at 1024 threads x 4); RES: every row block
+    uint32_t* s_bm = reinterpret_cast<uint32_t*>(s_frag + (RES ? (size_t)(res_tri_blocks + res_sph_blocks) * 128u : (size_t)kTB * kTileLoads));   // [BM][kTB] candidate words
+    unsigned long long* s_key = reinterpret_cast<unsigned long long*>(s_bm + BM * kTB);   // [kTB] nearest hit of every lane's ray
     uint32_t* s_pairs = reinterpret_cast<uint32_t*>(s_key + kTB);              // [waves][2][kPairCap]
     const uint32_t tid = threadIdx.x, lane = lane_id();
     uint32_t* pairs = s_pairs + (tid / 64u) * (3 * kPairCap);                  // (ray lane, row) pairs from the scan
@@ -889,6 +897,11 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
     uint32_t* lpairs = fpairs + kPairCap;                                      // SUP > 1: (ray lane, leaf group) pairs that passed the leaf's bound
     unsigned long long* keys = s_key + (tid & ~63u);                           // this wave's 64 records
     uint32_t* strip = A.pair_strips + ((size_t)blockIdx.x * (kTB / 64u) + tid / 64u) * kStripPairs;     // deferred member tests (GT, GS > 1)
+    if constexpr (RES) {                                                        // the rows: faces' first, then the spheres'
+        for (uint32_t k = tid; k < res_tri_blocks * 128u; k += kTB) s_frag[k] = tri_frags[k];
+        for (uint32_t k = tid; k < res_sph_blocks * 128u; k += kTB) s_frag[res_tri_blocks * 128u + k] = sph_frags[k];
+        __syncthreads();                                                        // the only barrier
+    }
 
     Path P;
     P.ox = P.oy = P.oz = 0.0f; P.dx = P.dy = 0.0f; P.dz = 1.0f;
@@ -908,7 +921,8 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
         // (no ray stock here: a ray cast costs at least one tile scan, start_path is noise beside it, and the stock's 8 registers are needed)
         refill_lanes<REF>(A, lane, alive, P, chunk_next, chunk_end, exhausted);
         const unsigned long long live = __ballot(alive);
-        if (!__syncthreads_or(live != 0ull ? 1 : 0)) break;                      // the workgroup ends together
+        if constexpr (RES) { if (live == 0ull) break; }                           // every wave for itself
+        else if (!__syncthreads_or(live != 0ull ? 1 : 0)) break;                 // tiles: the workgroup ends together
         casts += (unsigned long long)__popcll(live);
         LaneRay ray = { P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, REF && P.depth == 0 };
         float ux = ray.dx, uy = ray.dy, uz = ray.dz;                            // what the filter sees: always a unit direction
@@ -976,17 +990,21 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
             constexpr uint32_t kVec = K32 ? 128u : 256u;
             constexpr uint32_t kTile = kTB * kTileLoads / kVec;                 // row blocks per tile (64 KiB at 1024 threads x 4 loads): 32 | 16
             const uint32_t total_blocks = (n_rows + 31u) / 32u;
-            for (uint32_t b0 = 0; b0 < total_blocks; b0 += kTile) {
-                const uint32_t nb = min(kTile, total_blocks - b0);
-                RT3_PHASE(pt_rest)
-                fill_tile<kTB, kTileLoads>(s_frag, frags + (size_t)b0 * kVec, nb * kVec, tid);
-                RT3_PHASE(pt_fill)
-                if (live == 0ull) continue;                                     // a wave without rays (the tail of a launch) only keeps the barriers
-                for (uint32_t h0 = 0; h0 < nb; h0 += kBmBlocks) {               // the candidate words hold kBmBlocks row blocks: scan and push in parts
-                    const uint32_t hb = min(kBmBlocks, nb - h0);
+            for (uint32_t b0 = 0; b0 < total_blocks; b0 += RES ? total_blocks : kTile) {
+                const uint32_t nb = RES ? total_blocks : min(kTile, total_blocks - b0);
+                const u32x4* tile = s_frag;
+                if constexpr (RES) tile = s_frag + (frags == tri_frags ? 0u : res_tri_blocks * 128u);       // this pass's rows, resident
+                else {
+                    RT3_PHASE(pt_rest)
+                    fill_tile<kTB, kTileLoads>(s_frag, frags + (size_t)b0 * kVec, nb * kVec, tid);
+                    RT3_PHASE(pt_fill)
+                    if (live == 0ull) continue;                                 // a wave without rays (the tail of a launch) only keeps the barriers
+                }
+                for (uint32_t h0 = 0; h0 < nb; h0 += BM) {                      // the candidate words hold BM row blocks: scan and push in parts
+                    const uint32_t hb = min(BM, nb - h0);
                     uint32_t nz;
-                    if constexpr (K32) nz = mfma32k_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane, h0, 3);
-                    else nz = mfma16_scan_tile<kTB>(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
+                    if constexpr (K32) nz = mfma32k_scan_tile<kTB, !RES>(tile + (size_t)h0 * kVec, hb, R32, s_bm + tid, lane, h0, 3);
+                    else nz = mfma16_scan_tile<kTB>(tile + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
                     RT3_PHASE(pt_scan)
                     if constexpr (GROUPED) {
                         push_pairs16_spill<kTB>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, [&](uint32_t v) {
