@@ -1108,6 +1108,16 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
             } else {
                 // member m of a candidate group: the exact test on the member's record (group order), keyed by the sphere's own index
                 constexpr uint32_t LPP = kLanesPerPair < GS ? kLanesPerPair : GS, MPL = GS / LPP;   // lanes per pair, members per lane
+                // the exact test, on (ray lane, member position) pairs that passed its first half below — 64 at a time: the square root, the root choice
+                // and the key are ~40 instructions that 2 % of the member tests need, and a wave runs them whenever ONE of its 64 lanes does
+                auto sphere_exact = [&](uint32_t pair, bool valid) {
+                    const uint32_t src = pair >> kPairLaneShift, pos = pair & ((1u << kPairLaneShift) - 1u);
+                    const LaneRay r = fetch_ray<false>(ray, src);
+                    if (!valid) return;
+                    float t;
+                    if (sphere_root(A.sph_grp[pos], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff())
+                        atomicMin(&keys[src], hit_key(t, 1u, A.sph_perm[pos]));
+                };
                 auto sphere_group = [&](uint32_t pair, bool valid, uint32_t part) {
                     const uint32_t src = pair >> kPairLaneShift, g = pair & ((1u << kPairLaneShift) - 1u);
                     const LaneRay r = fetch_ray<false>(ray, src);
@@ -1119,9 +1129,22 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     for (uint32_t m = 0; m < MPL; m++) sm[m] = A.sph_grp[p0 + m];
 #pragma unroll
                     for (uint32_t m = 0; m < MPL; m++) {
-                        float t;
-                        if (ok && sphere_root(sm[m], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff())
-                            atomicMin(&keys[src], hit_key(t, 1u, A.sph_perm[p0 + m]));
+                        // sphere_root's own candidate rule, in its own arithmetic (rt3_kernel_common.hpp): whoever passes is tested in full
+                        const float cx = sm[m].x - r.ox, cy = sm[m].y - r.oy, cz = sm[m].z - r.oz;
+                        const float h = fma_(cz, r.dz, fma_(cy, r.dy, cx * r.dx));
+                        const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -sm[m].w)));
+                        const float disc = fma_(h, h, -c);
+                        const bool keep = ok && ((c < 0.0f) | ((disc > 0.0f) & (h > 0.0f)));
+                        const unsigned long long km = __ballot(keep);
+                        if (km == 0ull) continue;
+                        if (keep) fpairs[n_fpairs + prefix_count(km)] = (src << kPairLaneShift) | (p0 + m);
+                        n_fpairs += (uint32_t)__popcll(km);
+                        __builtin_amdgcn_wave_barrier();
+                        if (n_fpairs >= 64u) {
+                            n_fpairs -= 64u;
+                            sphere_exact(fpairs[n_fpairs + lane], true);
+                            __builtin_amdgcn_wave_barrier();
+                        }
                     }
                 };
                 if constexpr (SUP == 1) {
@@ -1130,6 +1153,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                              if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
                              drain_strip<LPP>(lane, strip, n_strip + n_pairs, sphere_group);
                              n_strip = 0u; n_pairs = 0u;
+                             test_all(lane, fpairs, n_fpairs, sphere_exact);
                          });
                 } else {
                     auto stage = super_stage(A.sph_leaf, A.n_sph_rows, std::integral_constant<uint32_t, LPP>(), sphere_group);
@@ -1139,6 +1163,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                              drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip + n_pairs, stage);
                              n_strip = 0u; n_pairs = 0u;
                              flush_leaves(std::integral_constant<uint32_t, LPP>(), sphere_group);
+                             test_all(lane, fpairs, n_fpairs, sphere_exact);
                          });
                 }
             }
