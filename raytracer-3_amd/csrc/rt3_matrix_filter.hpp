@@ -449,7 +449,40 @@ __device__ __forceinline__ void build_ray_operands32(float ox, float oy, float o
         R.b[0][i] = s0e; R.b[1][i] = s0o; R.b[2][i] = s1e; R.b[3][i] = s1o;
     }
 }
-// The scan: per row block 2 ds_read_b128, 8 MFMAs, 32 v_alignbit; candidate words exactly as mfma16_scan_tile's.
+// The scan: per row block 2 ds_read_b128, 8 MFMAs and the decode of their 32 results per lane into one candidate word (bit clear = candidate:
+// the sign bit of the result).
+// RT3_DECODE_FP6 = 1 (r3): ONE v_cvt_scalef32_2xpk16_fp6_f32 reads all 32 accumulators (2 x 16 registers) and writes 32 six-bit floats, each with the
+// sign of its input — zeros, denormals, underflow, overflow, infinities and NaNs of both signs included (tools/ubench_fp6_decode.hip checks every class
+// on the hardware).  It occupies the vector ALU AND the matrix pipe for 63-65 cycles (8 MFMAs + the conversion: 189 cycles per block with four waves
+// per SIMD, the conversion alone 65), where 32 v_alignbit_b32 take 117 in this kernel's instruction mix (158 on their own).  Input a[i] lands in field
+// 2 i, b[i] in field 2 i + 1, the sign of field f at bit 6 f + 5 of the 192: in the three words of a half the sign bits sit on DISJOINT odd positions
+// (5, 11, .. | 3, 9, .. | 1, 7, ..), so two v_bfi_b32 merge them, and one shift + v_bfi_b32 puts the second half on the even positions: 6 more
+// instructions.  Bit p of the word then belongs to field f = ((11 (p >> 1) + 10) & 15) + 16 (1 - (p & 1)) (3 f + 2 = p >> 1 mod 16), that is row half
+// h = f & 1, ray group G = f >> 3, accumulator j = (f >> 1) & 3 with a = (d0G), b = (d1G) below: cand_bit().  Measured in one process against the
+// v_alignbit build, identical frames (profiles/r03_ab_fp6_decode.log): headline kernel x0.95.  (Merging block b's words behind the MFMAs of block b + 1
+// changes nothing — x0.9495 against x0.9516 — the loop is bound by what the units are busy with, not by the wave's own latencies: not kept.)
+// RT3_DECODE_FP6 = 0: 32 v_alignbit_b32, bit 8 G + 4 h + j (the words of mfma16_scan_tile).
+#ifndef RT3_DECODE_FP6
+#define RT3_DECODE_FP6 1
+#endif
+#ifndef RT3_DECODE_MIX
+#define RT3_DECODE_MIX 0
+#endif
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x6v __attribute__((ext_vector_type(6)));
+__device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) {   // (a & mask) | (b & ~mask): ONE v_bfi_b32, mask in an SGPR
+    uint32_t d;                                                     // (left to itself the compiler prefers v_and_b32 with literals + v_or3_b32: 9 instead of 6)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+    return d;
+}
+// (G, h, j) of candidate bit `bit` of a word: ray group, row half, accumulator index
+template <bool FP6>
+__device__ __forceinline__ void cand_bit(uint32_t bit, uint32_t& G, uint32_t& h, uint32_t& j) {
+    if constexpr (FP6) {
+        const uint32_t f = ((11u * (bit >> 1) + 10u) & 15u) | ((~bit & 1u) << 4);
+        h = f & 1u; G = f >> 3; j = (f >> 1) & 3u;
+    } else { G = bit >> 3; h = (bit >> 2) & 1u; j = bit & 3u; }
+}
 template <uint32_t STRIDE = kMB, bool PRIO = true>                  // PRIO: progress priority (kernels whose waves meet at tile barriers)
 __device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint32_t n_blocks, const RayOperands32& R, uint32_t* bm, uint32_t lane,
                                                       uint32_t prio_base = 0, uint32_t prio_shift = 3) {
@@ -461,6 +494,17 @@ __device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint3
         const f32x4v zero = { 0.0f, 0.0f, 0.0f, 0.0f };
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), zero, 0, 0, 0);
     };
+    auto note = [&](uint32_t n, uint32_t* where) {                  // stores a candidate word, counts the words with a candidate
+        *where = n;
+        asm("v_cmp_ne_u32_e32 vcc, -1, %1\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(nz) : "v"(n) : "vcc");
+    };
+#if RT3_DECODE_FP6
+    auto merge = [](const u32x6v& r) {
+        const uint32_t t = bfi32(0x28A28A28u, bfi32(0x20820820u, r[0], r[1]), r[2]);      // odd bits: the signs of fields 0..15
+        const uint32_t v = bfi32(0x28A28A28u, bfi32(0x20820820u, r[3], r[4]), r[5]);      //           ... of fields 16..31
+        return bfi32(0xAAAAAAAAu, t, v >> 1);
+    };
+#endif
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += 4) {
         uint32_t* bm0 = bm + b0 * STRIDE;
 #if RT3_PROGRESS_PRIO
@@ -469,6 +513,26 @@ __device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint3
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             if (b0 + u >= n_blocks) break;
+#if RT3_DECODE_FP6
+            const f32x4v d00 = mm(a0, R.b[0]), d01 = mm(a0, R.b[1]), d02 = mm(a0, R.b[2]), d03 = mm(a0, R.b[3]);
+            const f32x4v d10 = mm(a1, R.b[0]), d11 = mm(a1, R.b[1]), d12 = mm(a1, R.b[2]), d13 = mm(a1, R.b[3]);
+            if (b0 + u + 1 < n_blocks) { const u32x4* fn = fr + (size_t)(b0 + u + 1) * 128; a0 = fn[0]; a1 = fn[64]; }
+            const f32x16v lo = { d00[0], d00[1], d00[2], d00[3], d01[0], d01[1], d01[2], d01[3], d02[0], d02[1], d02[2], d02[3], d03[0], d03[1], d03[2], d03[3] };
+            const f32x16v hi = { d10[0], d10[1], d10[2], d10[3], d11[0], d11[1], d11[2], d11[3], d12[0], d12[1], d12[2], d12[3], d13[0], d13[1], d13[2], d13[3] };
+#if RT3_DECODE_MIX
+            if (u % RT3_DECODE_MIX == RT3_DECODE_MIX - 1) {             // (experiment) every RT3_DECODE_MIX-th block on the vector ALU: the same word, bit by bit
+                uint32_t n = 0xFFFFFFFFu;
+#pragma unroll
+                for (int p = 31; p >= 0; p--) {
+                    const uint32_t f = ((11u * ((uint32_t)p >> 1) + 10u) & 15u) | ((~(uint32_t)p & 1u) << 4);
+                    const uint32_t i = f >> 1;
+                    n = __builtin_amdgcn_alignbit(n, __float_as_uint((f & 1u) ? hi[i] : lo[i]), 31);
+                }
+                note(n, bm0 + u * STRIDE);
+            } else
+#endif
+            note(merge(__builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(lo, hi, 1.0f)), bm0 + u * STRIDE);
+#else
             const f32x4v d13 = mm(a1, R.b[3]), d03 = mm(a0, R.b[3]), d12 = mm(a1, R.b[2]), d02 = mm(a0, R.b[2]);
             const f32x4v d11 = mm(a1, R.b[1]), d01 = mm(a0, R.b[1]), d10 = mm(a1, R.b[0]), d00 = mm(a0, R.b[0]);
             if (b0 + u + 1 < n_blocks) { const u32x4* fn = fr + (size_t)(b0 + u + 1) * 128; a0 = fn[0]; a1 = fn[64]; }
@@ -478,8 +542,8 @@ __device__ __forceinline__ uint32_t mfma32k_scan_tile(const u32x4* s_frag, uint3
             for (int k = 0; k < 8; k++)
 #pragma unroll
                 for (int j = 3; j >= 0; j--) n = __builtin_amdgcn_alignbit(n, __float_as_uint((*order[k])[j]), 31);
-            bm0[u * STRIDE] = n;
-            asm("v_cmp_ne_u32_e32 vcc, -1, %1\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(nz) : "v"(n) : "vcc");
+            note(n, bm0 + u * STRIDE);
+#endif
         }
     }
     return nz;
@@ -554,7 +618,7 @@ __device__ __forceinline__ void test_all(uint32_t lane, const uint32_t* pairs, u
 // Pushes this lane's candidates of the tile just scanned (rows row0 ..) into the wave's list and tests 64 pairs whenever that many are
 // there; n_pairs (wave-uniform) carries the remainder to the next tile.  The words are mfma16_scan_tile's: bit 8 G + 4 h + j of word blk
 // is (ray lane 16 G + c, row 32 blk + 16 h + 4 g + j), with (g, c) the pushing lane's own position.
-template <uint32_t STRIDE = kMB, class Test>
+template <uint32_t STRIDE = kMB, bool FP6 = false, class Test>
 __device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
                                              uint32_t& n_pairs, Test&& test) {
     CandIter it = { nz, 0u, 0u, n_blocks };
@@ -564,8 +628,9 @@ __device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, con
         const bool have = cand_next<STRIDE>(it, bm, pos);
         const unsigned long long m = __ballot(have);
         if (m == 0ull) break;
-        const uint32_t bit = pos & 31u;
-        const uint32_t row = row0 + (pos & ~31u) + ((bit & 4u) << 2) + g4 + (bit & 3u), ray_lane = ((bit >> 3) << 4) + c;
+        uint32_t G, h, j;
+        cand_bit<FP6>(pos & 31u, G, h, j);
+        const uint32_t row = row0 + (pos & ~31u) + (h << 4) + g4 + j, ray_lane = (G << 4) + c;
         if (have) pairs[n_pairs + prefix_count(m)] = (ray_lane << kPairLaneShift) | row;
         n_pairs += (uint32_t)__popcll(m);
         __builtin_amdgcn_wave_barrier();
@@ -585,10 +650,10 @@ __device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, con
 // owning lane once (ds_bpermute) and walks the group's members itself — their records are the lane's own 128 contiguous bytes — so the
 // per-pair overhead is paid once per GROUP member tests.  A strip holds kStripPairs pairs; a wave that fills it drains it on the spot.
 constexpr uint32_t kStripPairs = 8192;                              // per wave: 32 KiB (x 16 waves x 256 workgroups = 128 MiB)
-template <uint32_t STRIDE = kMB, class Spill>
+template <uint32_t STRIDE = kMB, bool FP6 = false, class Spill>
 __device__ __forceinline__ void push_pairs16_spill(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
                                                    uint32_t& n_pairs, Spill&& spill) {
-    push_pairs16<STRIDE>(nz, n_blocks, bm, row0, lane, pairs, n_pairs, [&](uint32_t v, bool) { spill(v); });
+    push_pairs16<STRIDE, FP6>(nz, n_blocks, bm, row0, lane, pairs, n_pairs, [&](uint32_t v, bool) { spill(v); });
 }
 // Runs `group(pair, valid, part)` — ALL lanes call it — on the n_strip pairs of the wave's strip.  LPP lanes share a pair: lane k of a batch takes
 // pair k / LPP and the members [part, part + 1) * GROUP / LPP of its group, part = k % LPP.  What LPP trades (100 000-sphere scene, per pair):
@@ -809,7 +874,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma32(const TraceArgs A, const u
         RT3_SPHASE(ph_operands)
         const uint32_t nz = mfma32k_scan_tile<kMB, false>(s_frag, n_blocks, R, s_bm + tid, lane);
         RT3_SPHASE(ph_scan)
-        push_pairs16<kMB>(nz, n_blocks, s_bm + tid, 0u, lane, pairs, n_pairs, test);
+        push_pairs16<kMB, RT3_DECODE_FP6 != 0>(nz, n_blocks, s_bm + tid, 0u, lane, pairs, n_pairs, test);
         test_all(lane, pairs, n_pairs, test);
         RT3_SPHASE(ph_flush)
         __builtin_amdgcn_wave_barrier();
@@ -1007,12 +1072,12 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     else nz = mfma16_scan_tile<kTB>(tile + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
                     RT3_PHASE(pt_scan)
                     if constexpr (GROUPED) {
-                        push_pairs16_spill<kTB>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, [&](uint32_t v) {
+                        push_pairs16_spill<kTB, K32 && RT3_DECODE_FP6 != 0>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, [&](uint32_t v) {
                             strip[n_strip + lane] = v;
                             n_strip += 64u;
                             if (n_strip + 64u > kStripPairs) { drain_strip<LPPX>(lane, strip, n_strip, test); n_strip = 0u; }    // (rare: 128 candidate rows per ray)
                         });
-                    } else push_pairs16<kTB>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
+                    } else push_pairs16<kTB, K32 && RT3_DECODE_FP6 != 0>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
                     RT3_PHASE(pt_push)
                     mfmas += hb * (K32 ? 8ull : 16ull);
                 }
@@ -1245,7 +1310,7 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
 #else
             const uint32_t nz = mfma16_scan_tile(s_frag + (size_t)h0 * kVec, hb, R, s_bm + tid, lane);
 #endif
-            push_pairs16(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
+            push_pairs16<kMB, RT3_FACE_K32 && RT3_DECODE_FP6>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
         }
     }
     test_all(lane, pairs, n_pairs, test);

@@ -106,3 +106,45 @@ def test_environment_switch_selects_the_flat_filter(renderer, name, monkeypatch)
     st_f = renderer.stats()
     if case.get("faces") is not None:                                     # (the sphere cases of this set run k_trace_mfma32: no rows to group)
         assert st_f.filter_tests == st_f.prim_tests and st.filter_tests < st_f.filter_tests
+
+
+@pytest.mark.parametrize("seed,n_faces,n_sph", [(21, 900, 0), (22, 0, 1100), (23, 1301, 707)])
+def test_tiled_rows_equal_resident_rows(rt3, renderer, seed, n_faces, n_sph, monkeypatch):
+    """Scenes whose rows fit in LDS run the barrier-free variant; RT3_NO_RESIDENT=1 streams the same rows through the 64-KiB tiles (the path
+    of scenes beyond 114 000 primitives): same frame, same counters."""
+    rng = np.random.default_rng(seed)
+    faces, verts, fm, cr, sm = random_soup(rng, n_faces, n_sph, 1.0, rt3)
+    cam = rt3.Camera().update(96, 64, 1.0, 3.0, 2.0)
+    case = dict(cam=cam.c, params=dict(width=96, height=64, spp=4, max_depth=6, seed=seed, flags=1, t_min=0.001))
+    if n_faces:
+        case.update(faces=faces, verts=verts, fmats=fm)
+    if n_sph:
+        case.update(spheres=cr, smats=sm)
+    resident = hip_render(renderer, case)
+    st_r = renderer.stats()
+    monkeypatch.setenv("RT3_NO_RESIDENT", "1")
+    tiled = hip_render(renderer, case, upload=False)
+    st_t = renderer.stats()
+    assert np.array_equal(tiled, resident)
+    assert (st_t.ray_casts, st_t.prim_tests) == (st_r.ray_casts, st_r.prim_tests)
+    renderer.force_brute(True)
+    try:
+        assert np.array_equal(hip_render(renderer, case, upload=False), resident)
+    finally:
+        renderer.force_brute(False)
+
+
+def test_scene_beyond_the_resident_limit_streams_its_rows(rt3, renderer):
+    """150 000 spheres + 3 000 faces: 2 344 + 47 rows of 64, more than LDS holds (56 row blocks of 16): the default path is the tiled
+    multi-level filter.  Against the flat filter and the unfiltered kernel on a small frame."""
+    cr, mats = rt3.scene_stress(150000, 9)
+    rng = np.random.default_rng(31)
+    faces, verts, fm, _, _ = random_soup(rng, 3000, 0, 1.0, rt3)
+    verts = verts.copy()
+    verts[:, :3] = verts[:, :3] * np.float32(3.0) + np.float32([0.0, 6.0, -30.0])
+    cam = rt3.Camera().look_at(96, 54, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
+    case = dict(spheres=cr, smats=mats, faces=faces, verts=verts, fmats=fm, cam=cam.c,
+                params=dict(width=96, height=54, spp=2, max_depth=8, seed=3, flags=1))
+    grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
+    assert np.array_equal(flat, brute) and np.array_equal(grouped, brute)
+    assert st_g.filter_tests // st_g.ray_casts > 56 * 16 and st_g.filter_tests * 50 < st_f.filter_tests

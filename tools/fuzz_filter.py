@@ -101,6 +101,13 @@ def run(count, first, r=None, log=print):
         if bad:
             bad_total += 1
             log("seed %d: %d pixels differ  %r" % (seed, bad, info))
+        if seed % 5 == 0:                                            # the same rows streamed through LDS tiles (the path of scenes > 114 000 primitives)
+            os.environ["RT3_NO_RESIDENT"] = "1"
+            tiled = r.render_path(cam.c, p)
+            del os.environ["RT3_NO_RESIDENT"]
+            if (tiled != ref).any():
+                bad_total += 1
+                log("seed %d: TILED ROWS %d pixels differ  %r" % (seed, int((tiled != ref).sum()), info))
         if (seed - first) % 50 == 49:
             log("... %d scenes, %d with differences" % (seed - first + 1, bad_total))
     log("fuzz: %d scenes, %d with differences" % (count, bad_total))
