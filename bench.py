@@ -11,11 +11,14 @@ puts them at their frame rows with one indexed copy.  Total work is fixed, so sc
 N = 1: the rows go through rt3_gather_rows (the C ABI's device-to-device gather), no collective.
 
 Prints one JSON line (rank 0).  Beside the driver's fields:
-  roofline         the dominant kernel (k_trace_mfma32) against the unit it saturates.  `bound` names that unit: "valu_issue" — the vector ALU's
-                   instruction issue, (SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4-cycle issue slots over the SIMD-cycles of the launch, ONE definition
-                   everywhere (README, DESIGN, profiles/README.md, extra_workloads) — with achieved / peak / frac in issue slots per second,
-                   from the committed rocprofv3 --pmc passes of this same command (only rocprofv3 can collect them), gated by the fingerprint
-                   of the kernel sources they were collected on.  `mfma` beside it is measured LIVE in this run: executed bf16 matrix FLOP
+  roofline         the dominant kernel (k_trace_mfma32) against the unit it saturates.  `bound` names that unit: "valu_busy" — the vector ALU:
+                   SQ_ACTIVE_INST_VALU x 4 cycles over the SIMD-cycles of the launch, ONE definition everywhere (README, DESIGN, profiles/README.md,
+                   extra_workloads).  The counter advances once per issued vector instruction and once more per further 4-cycle pass of a multi-pass
+                   one (measured: 17.8 per v_cvt_scalef32_2xpk16_fp6_f32, the 64-cycle block conversion that decodes 32 results; 1.2 per MFMA), so it
+                   is the time the unit is occupied whatever the instruction mix; round 2's instruction-slot figure ((SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4)
+                   sits beside it as `instruction_slot_frac` and no longer says how busy the unit is.  achieved / peak / frac come from the
+                   committed rocprofv3 --pmc passes of this same command (only rocprofv3 can collect them), gated by the fingerprint of the kernel
+                   sources they were collected on.  `mfma` beside it is measured LIVE in this run: executed bf16 matrix FLOP
                    (v_mfma_f32_16x16x32_bf16 instructions counted by the kernel itself x 16384) / kernel time from HIP events on the launch
                    stream, over the 2.5 PFLOP/s dense bf16 peak.  With a stale or missing profile `bound` falls back to "mfma" and the top-level
                    achieved / peak / frac are the live matrix figures (the counters are then null, never reused on other code)
@@ -129,7 +132,7 @@ def cpu_baseline(rt3, cr, mats, cam, budget_s):
 def counters_from_profile(fingerprint):
     """HBM traffic per k_trace launch and vector-ALU issue utilisation from the committed rocprofv3 --pmc passes of THIS command
     (tools/profile_final.sh).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE taken as is; both
-    count KiB.  Returns (traffic_bytes, traffic_source, valu_issue dict) — Nones when there is no profile or it is stale."""
+    count KiB.  Returns (traffic_bytes, traffic_source, valu_busy dict) — Nones when there is no profile or it is stale."""
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_PROFILE)))
     except (OSError, ValueError):
@@ -143,26 +146,29 @@ def counters_from_profile(fingerprint):
                        pmc["WRITE_SIZE"]["sum_over_dispatches"] / pmc["WRITE_SIZE"]["dispatches"]) * 1024)
         cycles = pmc["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0                     # SIMD-cycles over all dispatches
         n_valu = pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] - pmc["SQ_INSTS_MFMA"]["sum_over_dispatches"]
+        busy = pmc["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0
         disp = pmc["SQ_INSTS_VALU"]["dispatches"]
-        valu = {"frac": round(n_valu * 4.0 / cycles, 3),
-                "issue_slots_per_launch": int(n_valu / disp), "simd_quad_cycles_per_launch": int(cycles / 4.0 / disp),
+        valu = {"frac": round(busy / cycles, 3),
+                "busy_simd_cycles_per_launch": int(busy / disp), "simd_cycles_per_launch": int(cycles / disp),
                 "mfma_pipe_busy": round(pmc["SQ_VALU_MFMA_BUSY_CYCLES"]["sum_over_dispatches"] / cycles, 3),
-                "active_inst_valu_ratio": round(pmc["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0 / cycles, 3),
+                "instruction_slot_frac": round(n_valu * 4.0 / cycles, 3),
                 "valu_instructions_per_launch": int(pmc["SQ_INSTS_VALU"]["sum_over_dispatches"] / disp),
-                "source": src, "note": "frac = (SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 cycles / (1024 SIMDs x busy cycles): issue slots of the vector ALU "
-                                       "taken by its own (non-matrix) instructions, the resource this kernel saturates (tools/ubench_valu_rate.hip: a "
-                                       "v_alignbit / v_max / v_perm costs a SIMD 4.3 cycles with four waves resident, an FMA-class instruction 2.7-2.9, so "
-                                       "1 is not reachable with this mix); mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / the same SIMD-cycles; "
-                                       "active_inst_valu_ratio = SQ_ACTIVE_INST_VALU x 4 / the same cycles counts the matrix instructions too and is NOT "
-                                       "the issue fraction"}
+                "source": src, "note": "frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x busy cycles): the share of all SIMD-cycles in which the vector ALU "
+                                       "is occupied by an instruction — one count per issued vector instruction (matrix instructions included: their issue "
+                                       "occupies the same port) and one more per further 4-cycle pass of a multi-pass instruction (17.8 per "
+                                       "v_cvt_scalef32_2xpk16_fp6_f32: tools/ubench_fp6_decode.hip measures 63-65 cycles for it).  instruction_slot_frac = "
+                                       "(SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 / the same cycles is round 2's figure (0.913 when the decode was 32 v_alignbit_b32 "
+                                       "per row block; one conversion now does that work, so the instruction count fell and the unit is as busy as before); "
+                                       "mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / the same SIMD-cycles (matrix instructions only: the conversion, which also "
+                                       "holds the matrix pipe, is not in it)"}
         return traffic, src, valu
     except (KeyError, ZeroDivisionError):
         return None, "%s lacks FETCH_SIZE / WRITE_SIZE" % PMC_PROFILE, None
 
 
 def tiled_counters(fingerprint):
-    """VALU-issue fraction and matrix-pipe busy fraction of the kernels behind extra_workloads from profiles/r03_tiled_pmc.json (tools/profile_tiled.sh),
-    under the same rule as the headline's: only for the kernel sources they were collected on.  One definition: (VALU - MFMA instructions) x 4 / SIMD-cycles."""
+    """Vector-ALU busy fraction and matrix-pipe busy fraction of the kernels behind extra_workloads from profiles/r03_tiled_pmc.json (tools/profile_tiled.sh),
+    under the same rule as the headline's: only for the kernel sources they were collected on.  One definition: SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles."""
     try:
         pmc = json.load(open(os.path.join(ROOT, TILED_PMC_PROFILE)))
     except (OSError, ValueError):
@@ -175,7 +181,7 @@ def tiled_counters(fingerprint):
         if not isinstance(c, dict) or "SQ_BUSY_CYCLES" not in c:
             continue
         cycles = c["SQ_BUSY_CYCLES"]["sum_over_dispatches"] / 32.0 * 1024.0
-        out[key] = {"valu_issue": round((c["SQ_INSTS_VALU"]["sum_over_dispatches"] - c["SQ_INSTS_MFMA"]["sum_over_dispatches"]) * 4.0 / cycles, 3),
+        out[key] = {"valu_busy": round(c["SQ_ACTIVE_INST_VALU"]["sum_over_dispatches"] * 4.0 / cycles, 3),
                     "mfma_busy": round(c["SQ_VALU_MFMA_BUSY_CYCLES"]["sum_over_dispatches"] / cycles, 3)}
     return out, "%s (rocprofv3 --pmc passes of tools/run_config.py, kernel sources %s)" % (TILED_PMC_PROFILE, made_from)
 
@@ -225,7 +231,7 @@ def extra_workloads(rt3, r, np, fingerprint):
         d = {"workload": name, "kernel": kernel, "samples": int(st.samples), "ms": round(st.total_ms, 3),
              "msamples_per_s": round(st.samples / st.total_ms / 1e3, 2)}
         d.update(executed(st, k_slots))
-        d.update(counters.get(counter_key, {"valu_issue": None, "mfma_busy": None}))
+        d.update(counters.get(counter_key, {"valu_busy": None, "mfma_busy": None}))
         d["counters_source"] = counters_source
         out.append(d)
 
@@ -253,7 +259,7 @@ def extra_workloads(rt3, r, np, fingerprint):
                     "reference_cpu_s": MODE_R_REFERENCE_CPU_S, "speedup_vs_reference_cpu": round(MODE_R_REFERENCE_CPU_S / (ms * 1e-3), 0),
                     "note": "reference_cpu_s: the reference's SequentialRenderer on this frame, 1 thread, measured by the survey (SURVEY.md §6); "
                             "pixels equal the reference's PPM SHA-256 (tests/test_gpu_mode_r.py)",
-                    "counters_source": counters_source, **counters.get("config_r", {"valu_issue": None, "mfma_busy": None})})
+                    "counters_source": counters_source, **counters.get("config_r", {"valu_busy": None, "mfma_busy": None})})
         r.set_mesh(empty_f, empty_v)
     # (config 3 runs the headline kernel on the headline scene: leaving it out keeps k_trace_mfma32's rocprofv3 average = the headline launch)
     # config 4: 100 000 spheres
@@ -388,24 +394,24 @@ def main():
                     "live": True,
                     "note": "EXECUTED matrix work, measured in this run: wave-instructions counted by the kernel x FLOP per instruction / kernel time (HIP "
                             "events on the launch stream) over the dense bf16 peak.  The K = 32 filter (DESIGN.md 5.2b) needs half the matrix work per "
-                            "test of round 1's K = 64 form; the matrix pipe is about a third busy, the vector ALU beside it decodes one sign bit per pair"}
+                            "test of round 1's K = 64 form; the matrix pipe is about a third busy with them, and one block conversion per 8 of them (which holds the vector ALU and the matrix pipe for 64 cycles) reads the 32 signs"}
             common = {"kernel": "k_trace_mfma32" if k32 else "k_trace_mfma", "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(k_ms, 3),
                       "launches_per_step": launches, "kernel_sources": fingerprint, "mfma": mfma}
             if valu is not None:
-                roofline = dict(common, bound="valu_issue", achieved=valu["issue_slots_per_launch"], peak=valu["simd_quad_cycles_per_launch"],
-                                unit="4-cycle vector-ALU issue slots per launch (peak: SIMD-cycles / 4)", frac=valu["frac"], valu_issue=valu,
-                                live=["kernel_ms", "mfma (all of it)"],
-                                note="bound = the unit this kernel saturates: the vector ALU's own instructions fill `frac` of all 4-cycle issue slots of "
-                                     "the launch (hardware counters of the committed rocprofv3 passes of this command, valid for these kernel sources "
-                                     "only); the executed matrix fraction, measured live, is under `mfma`")
+                roofline = dict(common, bound="valu_busy", achieved=valu["busy_simd_cycles_per_launch"], peak=valu["simd_cycles_per_launch"],
+                                unit="SIMD-cycles per launch in which the vector ALU is occupied (peak: all SIMD-cycles of the launch)", frac=valu["frac"],
+                                valu_busy=valu, live=["kernel_ms", "mfma (all of it)"],
+                                note="bound = the unit this kernel saturates: the vector ALU is occupied in `frac` of all SIMD-cycles of the launch "
+                                     "(hardware counters of the committed rocprofv3 passes of this command, valid for these kernel sources only); the "
+                                     "executed matrix fraction, measured live, is under `mfma`")
             else:
-                roofline = dict(common, bound="mfma", achieved=mfma["achieved"], peak=mfma["peak"], unit=mfma["unit"], frac=mfma["frac"], valu_issue=None,
+                roofline = dict(common, bound="mfma", achieved=mfma["achieved"], peak=mfma["peak"], unit=mfma["unit"], frac=mfma["frac"], valu_busy=None,
                                 live=["achieved", "frac", "kernel_ms", "mfma"],
                                 note="no valid counter profile for this run (%s): the live executed-matrix fraction stands in; the kernel's binding "
-                                     "unit is vector-ALU issue (see profiles/README.md)" % traffic_source)
+                                     "unit is the vector ALU (see profiles/README.md)" % traffic_source)
         else:
-            roofline = {"bound": "valu_issue", "kernel": "k_trace (vector-ALU scan, RT3_NO_MFMA / RT3_BRUTE)", "achieved": None, "peak": None,
-                        "unit": "4-cycle vector-ALU issue slots per launch", "frac": None, "traffic": None, "traffic_source": "A/B build, not profiled",
+            roofline = {"bound": "valu_busy", "kernel": "k_trace (vector-ALU scan, RT3_NO_MFMA / RT3_BRUTE)", "achieved": None, "peak": None,
+                        "unit": "SIMD-cycles per launch in which the vector ALU is occupied", "frac": None, "traffic": None, "traffic_source": "A/B build, not profiled",
                         "kernel_ms": round(k_ms, 3), "launches_per_step": launches, "live": ["kernel_ms"], "mfma": None,
                         "note": "no matrix instructions issued by this kernel selection (A/B reference)"}
         out = {

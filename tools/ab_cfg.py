@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of two builds on the config-4 and config-5 shapes (global gathers in the exact test):
-    python tools/ab_cfg.py libA.so libB.so [libC.so ...]      (every library against the first)"""
+    python tools/ab_cfg.py libA.so libB.so [libC.so ...]      (every library against the first; AB_SPP=16,32 renders the two shapes at bench.py's
+                                                               16 / 32 samples per pixel instead of 2 / 2)"""
 import ctypes as C
 import importlib
 import os
@@ -24,12 +25,13 @@ def main():
         L.rt3_last_error.restype = C.c_char_p
         libs.append((L, C.c_void_p(L.rt3_create(0))))
     cases = []
+    spp4, spp5 = [int(v) for v in os.environ.get("AB_SPP", "2,2").split(",")]
     cr, mats = rt3.scene_stress(100000, 43)
     cam = rt3.Camera().look_at(1920, 1080, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
-    cases.append(("config 4 (100k spheres) 1920x1080x2", cam, rt3.make_params(1920, 1080, spp=2, max_depth=50, flags=1), ("sph", cr, mats)))
+    cases.append(("config 4 (100k spheres) 1920x1080x%d" % spp4, cam, rt3.make_params(1920, 1080, spp=spp4, max_depth=50, flags=1), ("sph", cr, mats)))
     faces, verts, fm = rt3.scene_cornell(64)
     cam = rt3.Camera().update(1024, 1024, 2.0, 2.0, 2.0)
-    cases.append(("config 5 (47k faces) 1024x1024x2", cam, rt3.make_params(1024, 1024, spp=2, max_depth=50, flags=3), ("tri", faces, verts, fm)))
+    cases.append(("config 5 (47k faces) 1024x1024x%d" % spp5, cam, rt3.make_params(1024, 1024, spp=spp5, max_depth=50, flags=3), ("tri", faces, verts, fm)))
     e_f, e_v = np.zeros(0, rt3.GFACE), np.zeros((0, 4), np.float32)
     for name, cam, p, scene in cases:
         outs, times = [], [[] for _ in libs]

@@ -5,6 +5,7 @@
 export TMPDIR=/tmp
 out=gpurun_out/final
 export RT3_PROFILE_TAG=${RT3_PROFILE_TAG:-r03}
+if [ -n "$RT3_TRACE_ONLY" ]; then mkdir -p $out; else
 rm -rf $out && mkdir -p $out
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" \
@@ -35,6 +36,7 @@ PY
 # the counters first, so that the traced run's JSON line reports them (bench.py reads profiles/${RT3_PROFILE_TAG}_bench_pmc_k_trace.json and
 # checks its source fingerprint)
 cp $out/pmc_k_trace.json profiles/${RT3_PROFILE_TAG}_bench_pmc_k_trace.json
+fi   # RT3_TRACE_ONLY=1: only the traced run below, with the committed counter profiles (its JSON line then carries the tiled kernels' counters too)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py > $out/bench_stdout.log 2>$out/bench_stderr.log || exit 1
 echo "trace pass done"
 grep '^{' $out/bench_stdout.log | tail -1 > $out/bench_line.json
