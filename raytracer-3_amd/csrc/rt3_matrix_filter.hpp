@@ -203,16 +203,16 @@ __device__ __forceinline__ uint32_t mfma_scan_tile(const u32x4* s_frag, uint32_t
 struct CandIter { uint32_t nz, bits, blk, nb; };
 template <uint32_t STRIDE = kMB>
 __device__ __forceinline__ bool cand_next(CandIter& it, const uint32_t* bm, uint32_t& row) {
-    if (it.bits == 0u) {
-        if (it.nz == 0u) return false;
+    if (it.bits == 0u && it.nz != 0u) {                             // (one divergent region; the rest is straight-line for every lane)
         const uint32_t hb = 31u - (uint32_t)__builtin_clz(it.nz);
         it.blk = it.nb - 1u - hb;
         it.nz ^= 1u << hb;
         it.bits = ~bm[it.blk * STRIDE];                             // non-zero: the scan set this word's nz bit
     }
-    row = it.blk * 32u + (uint32_t)__builtin_ctz(it.bits);
+    const bool have = it.bits != 0u;
+    row = it.blk * 32u + ((uint32_t)__ffs((int)it.bits) - 1u);      // (bits == 0: a value nobody uses)
     it.bits &= it.bits - 1u;
-    return true;
+    return have;
 }
 template <class Eval>
 __device__ __forceinline__ void mfma_flush(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, Eval&& eval) {
@@ -618,27 +618,45 @@ __device__ __forceinline__ void test_all(uint32_t lane, const uint32_t* pairs, u
 // Pushes this lane's candidates of the tile just scanned (rows row0 ..) into the wave's list and tests 64 pairs whenever that many are
 // there; n_pairs (wave-uniform) carries the remainder to the next tile.  The words are mfma16_scan_tile's: bit 8 G + 4 h + j of word blk
 // is (ray lane 16 G + c, row 32 blk + 16 h + 4 g + j), with (g, c) the pushing lane's own position.
+// The list holds RAW pairs (pushing lane << 26 | row0 + 32 blk + bit) and pair_decode() turns 64 of them into (ray lane << 26 | row) when they are
+// tested or set aside — the ten instructions of that arithmetic then run once per 64 pairs instead of once per trip of this loop, which goes at the pace of
+// the lane with the most candidates (7 trips for 2.45 candidates per lane on the bench scene).
+template <bool FP6>
+__device__ __forceinline__ uint32_t pair_decode(uint32_t raw) {
+    const uint32_t from = raw >> kPairLaneShift;
+    uint32_t G, h, j;
+    cand_bit<FP6>(raw & 31u, G, h, j);
+    return (((G << 4) + (from & 15u)) << kPairLaneShift) | ((raw & ((1u << kPairLaneShift) - 32u)) + (h << 4) + (from >> 4) * 4u + j);
+}
 template <uint32_t STRIDE = kMB, bool FP6 = false, class Test>
 __device__ __forceinline__ void push_pairs16(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
                                              uint32_t& n_pairs, Test&& test) {
     CandIter it = { nz, 0u, 0u, n_blocks };
-    const uint32_t c = lane & 15u, g4 = (lane >> 4) * 4u;
     for (;;) {
         uint32_t pos = 0;                                           // 32 blk + bit
         const bool have = cand_next<STRIDE>(it, bm, pos);
         const unsigned long long m = __ballot(have);
         if (m == 0ull) break;
-        uint32_t G, h, j;
-        cand_bit<FP6>(pos & 31u, G, h, j);
-        const uint32_t row = row0 + (pos & ~31u) + (h << 4) + g4 + j, ray_lane = (G << 4) + c;
-        if (have) pairs[n_pairs + prefix_count(m)] = (ray_lane << kPairLaneShift) | row;
+        const uint32_t pair = (lane << kPairLaneShift) | (row0 + pos);
+        if (have) pairs[n_pairs + prefix_count(m)] = pair;
         n_pairs += (uint32_t)__popcll(m);
         __builtin_amdgcn_wave_barrier();
         if (n_pairs >= 64u) {
             n_pairs -= 64u;
-            test(pairs[n_pairs + lane], true);
+            const uint32_t v = pairs[n_pairs + lane];
+            test(pair_decode<FP6>(v), true);
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+// What is left in a RAW list (see test_all).
+template <bool FP6, class Test>
+__device__ __forceinline__ void test_all_raw(uint32_t lane, const uint32_t* pairs, uint32_t& n_pairs, Test&& test) {
+    if (n_pairs != 0u) {
+        const bool valid = lane < n_pairs;
+        test(valid ? pair_decode<FP6>(pairs[lane]) : 0u, valid);
+        __builtin_amdgcn_wave_barrier();
+        n_pairs = 0u;
     }
 }
 
@@ -653,7 +671,7 @@ constexpr uint32_t kStripPairs = 8192;                              // per wave:
 template <uint32_t STRIDE = kMB, bool FP6 = false, class Spill>
 __device__ __forceinline__ void push_pairs16_spill(uint32_t nz, uint32_t n_blocks, const uint32_t* bm, uint32_t row0, uint32_t lane, uint32_t* pairs,
                                                    uint32_t& n_pairs, Spill&& spill) {
-    push_pairs16<STRIDE, FP6>(nz, n_blocks, bm, row0, lane, pairs, n_pairs, [&](uint32_t v, bool) { spill(v); });
+    push_pairs16<STRIDE, FP6>(nz, n_blocks, bm, row0, lane, pairs, n_pairs, [&](uint32_t v, bool) { spill(v); });   // (v: decoded by push_pairs16)
 }
 // Runs `group(pair, valid, part)` — ALL lanes call it — on the n_strip pairs of the wave's strip.  LPP lanes share a pair: lane k of a batch takes
 // pair k / LPP and the members [part, part + 1) * GROUP / LPP of its group, part = k % LPP.  What LPP trades (100 000-sphere scene, per pair):
@@ -875,7 +893,7 @@ __global__ __launch_bounds__(kMB) void k_trace_mfma32(const TraceArgs A, const u
         const uint32_t nz = mfma32k_scan_tile<kMB, false>(s_frag, n_blocks, R, s_bm + tid, lane);
         RT3_SPHASE(ph_scan)
         push_pairs16<kMB, RT3_DECODE_FP6 != 0>(nz, n_blocks, s_bm + tid, 0u, lane, pairs, n_pairs, test);
-        test_all(lane, pairs, n_pairs, test);
+        test_all_raw<RT3_DECODE_FP6 != 0>(lane, pairs, n_pairs, test);
         RT3_SPHASE(ph_flush)
         __builtin_amdgcn_wave_barrier();
         uint32_t kind, ibest;
@@ -1101,7 +1119,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
             };
             if constexpr (GT == 1) {
                 pass(tri_frags, A.n_tri_rows, std::bool_constant<RT3_FACE_K32 != 0>(), std::integral_constant<uint32_t, 1>(), face_test,
-                     [&]() { test_all(lane, pairs, n_pairs, face_test); });
+                     [&]() { test_all_raw<RT3_FACE_K32 && RT3_DECODE_FP6>(lane, pairs, n_pairs, face_test); });
             } else {
                 // member m of a candidate group: the member's own bounding sphere in f32 — scan_tile's arithmetic with its margin
                 // (rt3_valu_scan.hpp; what k_trace and k_mode_r_fast filter with), on the unit direction the filter saw — then the list of survivors
@@ -1140,7 +1158,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                 if constexpr (SUP == 1) {
                     pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, GT>(), face_group,
                          [&]() {
-                             if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                             if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
                              drain_strip<LPP>(lane, strip, n_strip + n_pairs, face_group);
                              n_strip = 0u; n_pairs = 0u;
                              test_all(lane, fpairs, n_fpairs, face_test);
@@ -1149,7 +1167,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     auto stage = super_stage(A.tri_leaf, A.n_tri_rows, std::integral_constant<uint32_t, LPP>(), face_group);
                     pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
                          [&]() {
-                             if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                             if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
                              drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip + n_pairs, stage);
                              n_strip = 0u; n_pairs = 0u;
                              flush_leaves(std::integral_constant<uint32_t, LPP>(), face_group);
@@ -1169,7 +1187,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     float t;
                     if (sphere_root(A.sph[j], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 1u, j));
                 };
-                pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, 1>(), test, [&]() { test_all(lane, pairs, n_pairs, test); });
+                pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, 1>(), test, [&]() { test_all_raw<RT3_DECODE_FP6 != 0>(lane, pairs, n_pairs, test); });
             } else {
                 // member m of a candidate group: the exact test on the member's record (group order), keyed by the sphere's own index
                 constexpr uint32_t LPP = kLanesPerPair < GS ? kLanesPerPair : GS, MPL = GS / LPP;   // lanes per pair, members per lane
@@ -1215,7 +1233,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                 if constexpr (SUP == 1) {
                     pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, GS>(), sphere_group,
                          [&]() {
-                             if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                             if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
                              drain_strip<LPP>(lane, strip, n_strip + n_pairs, sphere_group);
                              n_strip = 0u; n_pairs = 0u;
                              test_all(lane, fpairs, n_fpairs, sphere_exact);
@@ -1224,7 +1242,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     auto stage = super_stage(A.sph_leaf, A.n_sph_rows, std::integral_constant<uint32_t, LPP>(), sphere_group);
                     pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
                          [&]() {
-                             if (lane < n_pairs) strip[n_strip + lane] = pairs[lane];
+                             if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
                              drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip + n_pairs, stage);
                              n_strip = 0u; n_pairs = 0u;
                              flush_leaves(std::integral_constant<uint32_t, LPP>(), sphere_group);
@@ -1313,7 +1331,7 @@ __global__ __launch_bounds__(kMB) void k_mode_r_mfma(const float4* __restrict__ 
             push_pairs16<kMB, RT3_FACE_K32 && RT3_DECODE_FP6>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
         }
     }
-    test_all(lane, pairs, n_pairs, test);
+    test_all_raw<RT3_FACE_K32 && RT3_DECODE_FP6>(lane, pairs, n_pairs, test);
     __builtin_amdgcn_wave_barrier();
     if (!valid_px) return;
     uint32_t kind, min_i;
