@@ -465,6 +465,9 @@ __device__ __forceinline__ void build_ray_operands32(float ox, float oy, float o
 #ifndef RT3_DECODE_FP6
 #define RT3_DECODE_FP6 1
 #endif
+#ifndef RT3_PRUNE_BEHIND
+#define RT3_PRUNE_BEHIND 1
+#endif
 #ifndef RT3_DECODE_MIX
 #define RT3_DECODE_MIX 0
 #endif
@@ -1042,7 +1045,13 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     const float h = fma_(cz, sdz, fma_(cy, sdy, cx * sdx));
                     const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -b[m].w)));
                     const float disc = fma_(1e-4f, c, fma_(h, h, -c));
+#if RT3_PRUNE_BEHIND
+                    // a leaf whose centre lies behind an origin that is outside it meets only the backward half of the line (both roots < 0)
+                    const bool behind = (h < 0.0f) & (c > 2e-3f * b[m].w);
+                    const bool keep = ok && (((__float_as_uint(disc) >> 31) == 0u && !behind) || b[m].w >= 3e38f);
+#else
                     const bool keep = ok && ((__float_as_uint(disc) >> 31) == 0u || b[m].w >= 3e38f);   // (a leaf with an unbounded member: always)
+#endif
                     const unsigned long long km = __ballot(keep);
                     if (km == 0ull) continue;
                     if (keep) lpairs[n_lpairs + prefix_count(km)] = (src << kPairLaneShift) | (l0 + m);
@@ -1142,7 +1151,12 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                         const float disc = fma_(1e-5f, c, fma_(h, h, -c));
                         // the sign bit, as scan_tile reads it (padding: r^2 = -1e30); a face without a bounded hit region (r^2 = 3e38, possibly a
                         // non-finite centre) goes to the exact test whatever the arithmetic above made of it
+#if RT3_PRUNE_BEHIND
+                        const bool behind = (h < 0.0f) & (c > 2e-3f * b[m].w);
+                        const bool keep = valid && g < A.n_tri_leaves && (((__float_as_uint(disc) >> 31) == 0u && !behind) || b[m].w >= 3e38f);
+#else
                         const bool keep = valid && g < A.n_tri_leaves && ((__float_as_uint(disc) >> 31) == 0u || b[m].w >= 3e38f);
+#endif
                         const unsigned long long km = __ballot(keep);
                         if (km == 0ull) continue;
                         if (keep) fpairs[n_fpairs + prefix_count(km)] = (src << kPairLaneShift) | A.tri_perm[p0 + m];
