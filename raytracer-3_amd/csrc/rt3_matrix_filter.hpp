@@ -468,6 +468,9 @@ __device__ __forceinline__ void build_ray_operands32(float ox, float oy, float o
 #ifndef RT3_PRUNE_BEHIND
 #define RT3_PRUNE_BEHIND 1
 #endif
+#ifndef RT3_PRUNE_BEYOND
+#define RT3_PRUNE_BEYOND 1
+#endif
 #ifndef RT3_DECODE_MIX
 #define RT3_DECODE_MIX 0
 #endif
@@ -1025,8 +1028,9 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
         uint32_t n_pairs = 0, n_fpairs = 0, n_lpairs = 0, n_strip = 0;
         // SUP > 1: the middle level.  A batch of (ray lane, row) pairs, LPP lanes per pair, each lane SUP / LPP leaf bounds (its own contiguous bytes);
         // survivors are appended to lpairs and handed, 64 / LPP at a time, to `leaf_fn` (the members' tests of the two-level filter).
-        auto super_stage = [&](const float4* __restrict__ leaf_bounds, uint32_t n_rows, auto lpp_tag, auto&& leaf_fn) {
+        auto super_stage = [&](const float4* __restrict__ leaf_bounds, uint32_t n_rows, auto lpp_tag, auto beyond_tag, auto&& leaf_fn) {
             return [&, leaf_bounds, n_rows](uint32_t pair, bool valid, uint32_t part) {
+                constexpr bool BEYOND = decltype(beyond_tag)::value && !REF && RT3_PRUNE_BEYOND;   // (faces: x0.97; spheres: x1.01, off)
                 constexpr uint32_t LPPL = decltype(lpp_tag)::value;                 // lanes per pair of the LEAF stage: its batches take 64 / LPPL pairs
                 constexpr uint32_t LPPS = kLanesPerPair < SUP ? kLanesPerPair : SUP, MPLS = SUP / LPPS;
                 const uint32_t src = pair >> kPairLaneShift, g = pair & ((1u << kPairLaneShift) - 1u);
@@ -1035,6 +1039,8 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                 const float sdx = __shfl(ux, sl), sdy = __shfl(uy, sl), sdz = __shfl(uz, sl);
                 bound_tests += (unsigned long long)__popcll(__ballot(valid)) * MPLS;
                 const bool ok = valid && g < n_rows;
+                // the ray's best hit so far (its record in LDS; unit directions only: a literal reference ray counts t in its own units)
+                const float tb = BEYOND ? __uint_as_float(reinterpret_cast<const uint32_t*>(keys)[2u * src + 1u]) : __builtin_inff();
                 const uint32_t l0 = ok ? g * SUP + part * MPLS : 0u;
                 float4 b[MPLS];
 #pragma unroll
@@ -1047,7 +1053,11 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     const float disc = fma_(1e-4f, c, fma_(h, h, -c));
 #if RT3_PRUNE_BEHIND
                     // a leaf whose centre lies behind an origin that is outside it meets only the backward half of the line (both roots < 0)
-                    const bool behind = (h < 0.0f) & (c > 2e-3f * b[m].w);
+                    bool behind = (h < 0.0f) & (c > 2e-3f * b[m].w);
+                    // ... or that the ray only enters beyond its best hit so far: the point at t_best lies before the closest approach and outside
+                    // the leaf by a margin (|p(t_best) - C|^2 - R^2 = t_best^2 - 2 h t_best + c > 10^-3 |C - o|^2).  What it saves depends on the
+                    // order the pairs come in (47 106 faces: 7 % of the exact tests; 100 000 spheres: 11 % of the member tests, not worth 6 instructions)
+                    if constexpr (BEYOND) behind |= (tb < h) & (fma_(tb, fma_(-2.0f, h, tb), c) > 1e-3f * (c + b[m].w));
                     const bool keep = ok && (((__float_as_uint(disc) >> 31) == 0u && !behind) || b[m].w >= 3e38f);
 #else
                     const bool keep = ok && ((__float_as_uint(disc) >> 31) == 0u || b[m].w >= 3e38f);   // (a leaf with an unbounded member: always)
@@ -1178,7 +1188,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                              test_all(lane, fpairs, n_fpairs, face_test);
                          });
                 } else {
-                    auto stage = super_stage(A.tri_leaf, A.n_tri_rows, std::integral_constant<uint32_t, LPP>(), face_group);
+                    auto stage = super_stage(A.tri_leaf, A.n_tri_rows, std::integral_constant<uint32_t, LPP>(), std::true_type(), face_group);
                     pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
                          [&]() {
                              if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
@@ -1253,7 +1263,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                              test_all(lane, fpairs, n_fpairs, sphere_exact);
                          });
                 } else {
-                    auto stage = super_stage(A.sph_leaf, A.n_sph_rows, std::integral_constant<uint32_t, LPP>(), sphere_group);
+                    auto stage = super_stage(A.sph_leaf, A.n_sph_rows, std::integral_constant<uint32_t, LPP>(), std::false_type(), sphere_group);
                     pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
                          [&]() {
                              if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
