@@ -63,6 +63,7 @@ struct rt3_ctx {
     u32x4* d_tri_gfrag = nullptr; float4* d_tri_grp = nullptr; uint32_t* d_tri_perm = nullptr; uint32_t n_tri_groups = 0;
     u32x4* d_sph_gfrag = nullptr; float4* d_sph_grp = nullptr; uint32_t* d_sph_perm = nullptr; uint32_t n_sph_groups = 0;
     float4* d_tri_leaf = nullptr; float4* d_sph_leaf = nullptr; uint32_t n_tri_leaves = 0, n_sph_leaves = 0;      // three-level filter: the leaf groups' bounds
+    float4* d_tri_rowb = nullptr; float4* d_sph_rowb = nullptr;    // ... and the rows' own bounds in f32 (rows behind a ray are dropped before their leaves are tested)
     uint32_t* d_strips = nullptr; size_t strip_entries = 0;          // deferred member tests: kStripPairs pairs per wave of the grid
 
     // work buffers
@@ -437,7 +438,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r,
-                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips, ctx->d_tri_grp, ctx->d_tri_perm, ctx->d_tri_leaf, ctx->d_sph_leaf };
+                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips, ctx->d_tri_grp, ctx->d_tri_perm, ctx->d_tri_leaf, ctx->d_sph_leaf, ctx->d_tri_rowb, ctx->d_sph_rowb };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -514,7 +515,7 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
     for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in,
-                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm, (void**)&ctx->d_tri_leaf })
+                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm, (void**)&ctx->d_tri_leaf, (void**)&ctx->d_tri_rowb })
         if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
     ctx->n_faces = 0; ctx->n_tri_groups = 0;
     if (n == 0) return 0;
@@ -589,6 +590,12 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
         hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_members, row_entries,
                            row_group, n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_gfrag);
         RT3_HIP(hipGetLastError());
+        if (kSuper > 1) {                                           // the same rows as f32 records
+            RT3_HIP(hipMalloc((void**)&ctx->d_tri_rowb, (size_t)n_group_rows * sizeof(float4)));
+            hipLaunchKernelGGL(k_group_bounds, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_members, row_entries,
+                               row_group, n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_rowb);
+            RT3_HIP(hipGetLastError());
+        }
         RT3_HIP(hipStreamSynchronize(ctx->stream));                 // a render may come on another stream
     }
     ctx->n_faces = n;
@@ -644,7 +651,7 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
         std::vector<float4> grp(order.size(), kPadSphere);
         for (size_t k = 0; k < order.size(); k++) if (order[k] != 0xFFFFFFFFu) grp[k] = sph[order[k]];
         if ((rc = upload(ctx, &ctx->d_sph_grp, grp)) || (rc = upload(ctx, &ctx->d_sph_perm, order))) return rc;
-        for (void** b : { (void**)&ctx->d_sph_gfrag, (void**)&ctx->d_sph_leaf }) if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
+        for (void** b : { (void**)&ctx->d_sph_gfrag, (void**)&ctx->d_sph_leaf, (void**)&ctx->d_sph_rowb }) if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
         ctx->n_sph_leaves = (uint32_t)(order.size() / kGroupSph);
         ctx->n_sph_groups = ctx->n_sph_leaves / kSuper;                // rows the matrix filter scans
         if (ctx->n_sph_groups) {
@@ -663,6 +670,12 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
             hipLaunchKernelGGL(k_group_frags, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_members, row_entries, row_group,
                                n_group_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2], ctx->d_sph_gfrag);
             RT3_HIP(hipGetLastError());
+            if (kSuper > 1) {
+                RT3_HIP(hipMalloc((void**)&ctx->d_sph_rowb, (size_t)n_group_rows * sizeof(float4)));
+                hipLaunchKernelGGL(k_group_bounds, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_members, row_entries, row_group,
+                                   n_group_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2], ctx->d_sph_rowb);
+                RT3_HIP(hipGetLastError());
+            }
             RT3_HIP(hipStreamSynchronize(ctx->stream));             // a render may come on another stream
         }
     }
@@ -871,6 +884,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     A.n_sph_rows = grouped ? ctx->n_sph_groups : ctx->n_sph;
     A.sph_grp = ctx->d_sph_grp; A.sph_perm = ctx->d_sph_perm; A.tri_grp = ctx->d_tri_grp; A.tri_perm = ctx->d_tri_perm;
     A.tri_leaf = ctx->d_tri_leaf; A.sph_leaf = ctx->d_sph_leaf; A.n_tri_leaves = ctx->n_tri_leaves; A.n_sph_leaves = ctx->n_sph_leaves;
+    A.tri_rowb = ctx->d_tri_rowb; A.sph_rowb = ctx->d_sph_rowb;
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;
     TraceKernel plain = nullptr;
     TiledKernel tiled = nullptr;

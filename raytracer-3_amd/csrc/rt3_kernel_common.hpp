@@ -138,6 +138,7 @@ struct TraceArgs {
     // Three levels (kSuper > 1): a row bounds kSuper consecutive LEAF groups; *_leaf holds the leaves' bounding spheres (cx, cy, cz, R_eff^2), which a
     // candidate row's rays are tested against in f32 before the leaves' members are.  n_*_leaves: leaf groups (= rows x kSuper).
     const float4* sph_leaf; const float4* tri_leaf; uint32_t n_sph_leaves, n_tri_leaves;
+    const float4* sph_rowb; const float4* tri_rowb;                 // three-level filter: the rows' own bounds (C, R_eff^2) in f32, or null
     uint32_t* pair_strips;   // [wave of the grid][kStripPairs]: candidate (ray lane, row) pairs set aside for the end of a pass (deferred member tests)
     uint32_t* work_counter;
     unsigned long long* cast_counter;

@@ -471,6 +471,9 @@ __device__ __forceinline__ void build_ray_operands32(float ox, float oy, float o
 #ifndef RT3_PRUNE_BEYOND
 #define RT3_PRUNE_BEYOND 1
 #endif
+#ifndef RT3_PRUNE_ROWS
+#define RT3_PRUNE_ROWS 1
+#endif
 #ifndef RT3_DECODE_MIX
 #define RT3_DECODE_MIX 0
 #endif
@@ -1085,7 +1088,36 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
             }
         };
 
-        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, auto k32, auto group_tag, auto&& test, auto&& finish) {
+        // Sets (ray lane, row) pairs aside in the wave's strip — ALL lanes call it — after one more look at the ROW's own bound (rowb; three-level filter):
+        // the matrix filter tested the line, a row that lies behind the ray's origin (centre behind, origin outside: both roots negative) or, for
+        // faces, that the ray enters only beyond its best hit so far costs eight leaf tests for nothing.  One lane per pair: 64 at a time.
+        auto set_aside = [&](uint32_t v, bool valid, const float4* __restrict__ rowb, auto beyond_tag) {
+            bool keep = valid;
+#if RT3_PRUNE_ROWS
+            if (rowb != nullptr) {
+                const uint32_t src = v >> kPairLaneShift, g = v & ((1u << kPairLaneShift) - 1u);
+                const int sl = (int)src;
+                const float sox = __shfl(ray.ox, sl), soy = __shfl(ray.oy, sl), soz = __shfl(ray.oz, sl);
+                const float sdx = __shfl(ux, sl), sdy = __shfl(uy, sl), sdz = __shfl(uz, sl);
+                const float4 b = rowb[valid ? g : 0u];
+                const float cx = b.x - sox, cy = b.y - soy, cz = b.z - soz;
+                const float h = fma_(cz, sdz, fma_(cy, sdy, cx * sdx));
+                const float c = fma_(cz, cz, fma_(cy, cy, fma_(cx, cx, -b.w)));
+                bool drop = (h < 0.0f) & (c > 2e-3f * b.w);
+                if constexpr (decltype(beyond_tag)::value && !REF && RT3_PRUNE_BEYOND) {
+                    const float tb = __uint_as_float(reinterpret_cast<const uint32_t*>(keys)[2u * src + 1u]);
+                    drop |= (tb < h) & (fma_(tb, fma_(-2.0f, h, tb), c) > 1e-3f * (c + b.w));
+                }
+                keep = valid && !drop;
+                bound_tests += (unsigned long long)__popcll(__ballot(valid));
+            }
+#endif
+            const unsigned long long km = __ballot(keep);
+            if (keep) strip[n_strip + prefix_count(km)] = v;
+            n_strip += (uint32_t)__popcll(km);
+        };
+
+        auto pass = [&](const u32x4* __restrict__ frags, uint32_t n_rows, const float4* __restrict__ rowb, auto beyond_tag, auto k32, auto group_tag, auto&& test, auto&& finish) {
             constexpr bool K32 = decltype(k32)::value;                          // spheres: 2 operand fragments (2 KiB) per row block, else 4
             constexpr bool GROUPED = decltype(group_tag)::value > 1;            // `test` is then the deferred (pair, valid, part) form
             constexpr uint32_t LPPX = kLanesPerPair < decltype(group_tag)::value ? kLanesPerPair : decltype(group_tag)::value;
@@ -1110,8 +1142,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     RT3_PHASE(pt_scan)
                     if constexpr (GROUPED) {
                         push_pairs16_spill<kTB, K32 && RT3_DECODE_FP6 != 0>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, [&](uint32_t v) {
-                            strip[n_strip + lane] = v;
-                            n_strip += 64u;
+                            set_aside(v, true, rowb, beyond_tag);
                             if (n_strip + 64u > kStripPairs) { drain_strip<LPPX>(lane, strip, n_strip, test); n_strip = 0u; }    // (rare: 128 candidate rows per ray)
                         });
                     } else push_pairs16<kTB, K32 && RT3_DECODE_FP6 != 0>(nz, hb, s_bm + tid, (b0 + h0) * 32u, lane, pairs, n_pairs, test);
@@ -1137,7 +1168,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                 if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
             };
             if constexpr (GT == 1) {
-                pass(tri_frags, A.n_tri_rows, std::bool_constant<RT3_FACE_K32 != 0>(), std::integral_constant<uint32_t, 1>(), face_test,
+                pass(tri_frags, A.n_tri_rows, (const float4*)nullptr, std::false_type(), std::bool_constant<RT3_FACE_K32 != 0>(), std::integral_constant<uint32_t, 1>(), face_test,
                      [&]() { test_all_raw<RT3_FACE_K32 && RT3_DECODE_FP6>(lane, pairs, n_pairs, face_test); });
             } else {
                 // member m of a candidate group: the member's own bounding sphere in f32 — scan_tile's arithmetic with its margin
@@ -1180,19 +1211,19 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     }
                 };
                 if constexpr (SUP == 1) {
-                    pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, GT>(), face_group,
+                    pass(tri_frags, A.n_tri_rows, (const float4*)nullptr, std::false_type(), std::true_type(), std::integral_constant<uint32_t, GT>(), face_group,
                          [&]() {
-                             if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
-                             drain_strip<LPP>(lane, strip, n_strip + n_pairs, face_group);
+                             { const bool lv = lane < n_pairs; set_aside(lv ? pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]) : 0u, lv, (const float4*)nullptr, std::false_type()); }
+                             drain_strip<LPP>(lane, strip, n_strip, face_group);
                              n_strip = 0u; n_pairs = 0u;
                              test_all(lane, fpairs, n_fpairs, face_test);
                          });
                 } else {
                     auto stage = super_stage(A.tri_leaf, A.n_tri_rows, std::integral_constant<uint32_t, LPP>(), std::true_type(), face_group);
-                    pass(tri_frags, A.n_tri_rows, std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
+                    pass(tri_frags, A.n_tri_rows, A.tri_rowb, std::true_type(), std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
                          [&]() {
-                             if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
-                             drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip + n_pairs, stage);
+                             { const bool lv = lane < n_pairs; set_aside(lv ? pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]) : 0u, lv, A.tri_rowb, std::true_type()); }
+                             drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip, stage);
                              n_strip = 0u; n_pairs = 0u;
                              flush_leaves(std::integral_constant<uint32_t, LPP>(), face_group);
                              test_all(lane, fpairs, n_fpairs, face_test);
@@ -1211,7 +1242,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     float t;
                     if (sphere_root(A.sph[j], r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, A.t_min, t) && t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 1u, j));
                 };
-                pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, 1>(), test, [&]() { test_all_raw<RT3_DECODE_FP6 != 0>(lane, pairs, n_pairs, test); });
+                pass(sph_frags, A.n_sph_rows, (const float4*)nullptr, std::false_type(), std::true_type(), std::integral_constant<uint32_t, 1>(), test, [&]() { test_all_raw<RT3_DECODE_FP6 != 0>(lane, pairs, n_pairs, test); });
             } else {
                 // member m of a candidate group: the exact test on the member's record (group order), keyed by the sphere's own index
                 constexpr uint32_t LPP = kLanesPerPair < GS ? kLanesPerPair : GS, MPL = GS / LPP;   // lanes per pair, members per lane
@@ -1255,19 +1286,19 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
                     }
                 };
                 if constexpr (SUP == 1) {
-                    pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, GS>(), sphere_group,
+                    pass(sph_frags, A.n_sph_rows, (const float4*)nullptr, std::false_type(), std::true_type(), std::integral_constant<uint32_t, GS>(), sphere_group,
                          [&]() {
-                             if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
-                             drain_strip<LPP>(lane, strip, n_strip + n_pairs, sphere_group);
+                             { const bool lv = lane < n_pairs; set_aside(lv ? pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]) : 0u, lv, (const float4*)nullptr, std::false_type()); }
+                             drain_strip<LPP>(lane, strip, n_strip, sphere_group);
                              n_strip = 0u; n_pairs = 0u;
                              test_all(lane, fpairs, n_fpairs, sphere_exact);
                          });
                 } else {
                     auto stage = super_stage(A.sph_leaf, A.n_sph_rows, std::integral_constant<uint32_t, LPP>(), std::false_type(), sphere_group);
-                    pass(sph_frags, A.n_sph_rows, std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
+                    pass(sph_frags, A.n_sph_rows, A.sph_rowb, std::false_type(), std::true_type(), std::integral_constant<uint32_t, SUP>(), stage,
                          [&]() {
-                             if (lane < n_pairs) strip[n_strip + lane] = pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]);
-                             drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip + n_pairs, stage);
+                             { const bool lv = lane < n_pairs; set_aside(lv ? pair_decode<RT3_DECODE_FP6 != 0>(pairs[lane]) : 0u, lv, A.sph_rowb, std::false_type()); }
+                             drain_strip<(kLanesPerPair < SUP ? kLanesPerPair : SUP)>(lane, strip, n_strip, stage);
                              n_strip = 0u; n_pairs = 0u;
                              flush_leaves(std::integral_constant<uint32_t, LPP>(), sphere_group);
                              test_all(lane, fpairs, n_fpairs, sphere_exact);
