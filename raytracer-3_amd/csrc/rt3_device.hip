@@ -37,6 +37,7 @@
 #include "rt3_path.hpp"
 #include "rt3_valu_scan.hpp"
 #include "rt3_matrix_filter.hpp"
+#include "rt3_level_filter.hpp"
 #include "rt3_reduce.hpp"
 #include "rt3_scene_kernels.hpp"
 
@@ -64,6 +65,8 @@ struct rt3_ctx {
     u32x4* d_sph_gfrag = nullptr; float4* d_sph_grp = nullptr; uint32_t* d_sph_perm = nullptr; uint32_t n_sph_groups = 0;
     float4* d_tri_leaf = nullptr; float4* d_sph_leaf = nullptr; uint32_t n_tri_leaves = 0, n_sph_leaves = 0;      // three-level filter: the leaf groups' bounds
     float4* d_tri_rowb = nullptr; float4* d_sph_rowb = nullptr;    // ... and the rows' own bounds in f32 (rows behind a ray are dropped before their leaves are tested)
+    u32x4* d_tri_sfrag = nullptr; u32x4* d_sph_sfrag = nullptr; float4* d_tri_srowb = nullptr; float4* d_sph_srowb = nullptr;   // four levels: super-rows of kSuper rows
+    uint32_t n_tri_super = 0, n_sph_super = 0;
     uint32_t* d_strips = nullptr; size_t strip_entries = 0;          // deferred member tests: kStripPairs pairs per wave of the grid
 
     // work buffers
@@ -438,7 +441,8 @@ void rt3_destroy(rt3_ctx* ctx) {
     (void)hipDeviceSynchronize();
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r,
-                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips, ctx->d_tri_grp, ctx->d_tri_perm, ctx->d_tri_leaf, ctx->d_sph_leaf, ctx->d_tri_rowb, ctx->d_sph_rowb };
+                     ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips, ctx->d_tri_grp, ctx->d_tri_perm, ctx->d_tri_leaf, ctx->d_sph_leaf, ctx->d_tri_rowb, ctx->d_sph_rowb,
+                     ctx->d_tri_sfrag, ctx->d_sph_sfrag, ctx->d_tri_srowb, ctx->d_sph_srowb };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -515,9 +519,9 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
     for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in,
-                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm, (void**)&ctx->d_tri_leaf, (void**)&ctx->d_tri_rowb })
+                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm, (void**)&ctx->d_tri_leaf, (void**)&ctx->d_tri_rowb, (void**)&ctx->d_tri_sfrag, (void**)&ctx->d_tri_srowb })
         if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
-    ctx->n_faces = 0; ctx->n_tri_groups = 0;
+    ctx->n_faces = 0; ctx->n_tri_groups = 0; ctx->n_tri_super = 0;
     if (n == 0) return 0;
     if (face_materials)
         for (uint32_t i = 0; i < n; i++)
@@ -595,6 +599,16 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
             hipLaunchKernelGGL(k_group_bounds, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_members, row_entries,
                                row_group, n_group_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_rowb);
             RT3_HIP(hipGetLastError());
+            // four levels: super-rows of kSuper rows, as fragments for the matrix filter and as f32 records
+            ctx->n_tri_super = (ctx->n_tri_groups + kSuper - 1u) / kSuper;
+            const uint32_t n_super_rows = (ctx->n_tri_super + 31u) / 32u * 32u;
+            RT3_HIP(hipMalloc((void**)&ctx->d_tri_sfrag, (size_t)n_super_rows * 4 * sizeof(u32x4)));
+            RT3_HIP(hipMalloc((void**)&ctx->d_tri_srowb, (size_t)n_super_rows * sizeof(float4)));
+            hipLaunchKernelGGL(k_group_frags, dim3((n_super_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_rowb, n_group_rows,
+                               kSuper, n_super_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_sfrag);
+            hipLaunchKernelGGL(k_group_bounds, dim3((n_super_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri_rowb, n_group_rows,
+                               kSuper, n_super_rows, (const uint32_t*)ctx->d_box, 0.0f, 0.0f, 0.0f, ctx->d_tri_srowb);
+            RT3_HIP(hipGetLastError());
         }
         RT3_HIP(hipStreamSynchronize(ctx->stream));                 // a render may come on another stream
     }
@@ -651,9 +665,11 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
         std::vector<float4> grp(order.size(), kPadSphere);
         for (size_t k = 0; k < order.size(); k++) if (order[k] != 0xFFFFFFFFu) grp[k] = sph[order[k]];
         if ((rc = upload(ctx, &ctx->d_sph_grp, grp)) || (rc = upload(ctx, &ctx->d_sph_perm, order))) return rc;
-        for (void** b : { (void**)&ctx->d_sph_gfrag, (void**)&ctx->d_sph_leaf, (void**)&ctx->d_sph_rowb }) if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
+        for (void** b : { (void**)&ctx->d_sph_gfrag, (void**)&ctx->d_sph_leaf, (void**)&ctx->d_sph_rowb, (void**)&ctx->d_sph_sfrag, (void**)&ctx->d_sph_srowb })
+            if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
         ctx->n_sph_leaves = (uint32_t)(order.size() / kGroupSph);
         ctx->n_sph_groups = ctx->n_sph_leaves / kSuper;                // rows the matrix filter scans
+        ctx->n_sph_super = 0;                                          // (no groups: every sphere is on the direct list or unusable)
         if (ctx->n_sph_groups) {
             const float4* row_members = ctx->d_sph_grp;
             uint32_t row_entries = (uint32_t)order.size(), row_group = kGroupSph;
@@ -674,6 +690,15 @@ int rt3_set_spheres(rt3_ctx* ctx, const float* center_radius, const rt3_material
                 RT3_HIP(hipMalloc((void**)&ctx->d_sph_rowb, (size_t)n_group_rows * sizeof(float4)));
                 hipLaunchKernelGGL(k_group_bounds, dim3((n_group_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, row_members, row_entries, row_group,
                                    n_group_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2], ctx->d_sph_rowb);
+                RT3_HIP(hipGetLastError());
+                ctx->n_sph_super = (ctx->n_sph_groups + kSuper - 1u) / kSuper;
+                const uint32_t n_super_rows = (ctx->n_sph_super + 31u) / 32u * 32u;
+                RT3_HIP(hipMalloc((void**)&ctx->d_sph_sfrag, (size_t)n_super_rows * 4 * sizeof(u32x4)));
+                RT3_HIP(hipMalloc((void**)&ctx->d_sph_srowb, (size_t)n_super_rows * sizeof(float4)));
+                hipLaunchKernelGGL(k_group_frags, dim3((n_super_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_sph_rowb, n_group_rows, kSuper,
+                                   n_super_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2], ctx->d_sph_sfrag);
+                hipLaunchKernelGGL(k_group_bounds, dim3((n_super_rows + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_sph_rowb, n_group_rows, kSuper,
+                                   n_super_rows, (const uint32_t*)nullptr, ctx->sph_centre[0], ctx->sph_centre[1], ctx->sph_centre[2], ctx->d_sph_srowb);
                 RT3_HIP(hipGetLastError());
             }
             RT3_HIP(hipStreamSynchronize(ctx->stream));             // a render may come on another stream
@@ -889,6 +914,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     TraceKernel plain = nullptr;
     TiledKernel tiled = nullptr;
     bool resident = false;
+    uint32_t levels = 0;                                            // k_trace_levels: 3 | 4
     size_t lds = 0;
     int block = kBlock;
     const void* kptr = nullptr;
@@ -905,6 +931,25 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         // the two-level filter (rows = groups of primitives) unless RT3_NO_GROUPS=1 asks for the flat one (A/B reference, tests)
         constexpr uint32_t GT = kGroupTri, GS = kGroupSph, SUP = kSuper;
         const uint32_t row_blocks = (has_tri ? (A.n_tri_rows + 31u) / 32u : 0u) + (has_sph ? (A.n_sph_rows + 31u) / 32u : 0u);
+        const uint32_t super_blocks = (has_tri ? (ctx->n_tri_super + 31u) / 32u : 0u) + (has_sph ? (ctx->n_sph_super + 31u) / 32u : 0u);
+        // While the rows of 64 fit in LDS (<= kResidentBlocks row blocks, 114 000 primitives: both BASELINE scenes) k_trace_mfma_tiled's resident three-level
+        // form runs; beyond, k_trace_levels (rt3_level_filter.hpp) with FOUR levels — the matrix cores scan super-rows of 512, resident up to 590 000
+        // primitives, through a tile after that.  RT3_LEVELS=3|4 forces k_trace_levels with that many levels, RT3_OLD_GROUPS=1 the nested form (A/B, tests)
+        const char* force_levels = getenv("RT3_LEVELS");
+        const bool no_res_env = getenv("RT3_NO_RESIDENT") != nullptr;
+        const bool lev_kernel = grouped && SUP > 1 && !getenv("RT3_OLD_GROUPS") && (force_levels != nullptr || row_blocks > kResidentBlocks);
+        if (lev_kernel) {
+            levels = force_levels ? (atoi(force_levels) == 4 ? 4u : 3u) : 4u;
+            const uint32_t top_blocks = levels == 4 ? super_blocks : row_blocks;
+            resident = !no_res_env && top_blocks <= lev_resident_blocks(levels);
+            A.n_tri_top = levels == 4 ? ctx->n_tri_super : ctx->n_tri_groups; A.n_sph_top = levels == 4 ? ctx->n_sph_super : ctx->n_sph_groups;
+            A.tri_topb = levels == 4 ? ctx->d_tri_srowb : ctx->d_tri_rowb; A.sph_topb = levels == 4 ? ctx->d_sph_srowb : ctx->d_sph_rowb;
+#define RT3_LEV(L, R) (has_tri ? (has_sph ? k_trace_levels<true, true, false, L, R> : (ref ? k_trace_levels<true, false, true, L, R> : k_trace_levels<true, false, false, L, R>)) \
+                               : k_trace_levels<false, true, false, L, R>)
+            tiled = levels == 4 ? (resident ? RT3_LEV(4, true) : RT3_LEV(4, false)) : (resident ? RT3_LEV(3, true) : RT3_LEV(3, false));
+#undef RT3_LEV
+            lds = lev_lds_fixed(levels, resident) + (resident ? (size_t)top_blocks * 2048u : 0u);
+        } else {
         resident = grouped && SUP > 1 && row_blocks <= kResidentBlocks && !getenv("RT3_NO_RESIDENT");      // all rows fit in LDS: no tiles, no barriers
         if (resident)
             tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false, GT, GS, SUP, true> : (ref ? k_trace_mfma_tiled<true, false, true, GT, 1, SUP, true> : k_trace_mfma_tiled<true, false, false, GT, 1, SUP, true>))
@@ -916,6 +961,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
             tiled = has_tri ? (has_sph ? k_trace_mfma_tiled<true, true, false> : (ref ? k_trace_mfma_tiled<true, false, true> : k_trace_mfma_tiled<true, false, false>))
                             : k_trace_mfma_tiled<false, true, false>;
         lds = resident ? (size_t)row_blocks * 2048u + (size_t)kBmBlocksRes * kTB * 4u + (size_t)kTB * 8u + (size_t)(kTB / 64u) * kPairCap * 4u * 3u : kTraceTiledLdsBytes;
+        }
         block = kTB;
         kptr = (const void*)tiled;
 
@@ -954,6 +1000,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         RT3_HIP(hipEventRecord(a, stream));
         if (mfma_single && single_k64) hipLaunchKernelGGL(k_trace_mfma, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag, mfma_blocks);
         else if (mfma_single) hipLaunchKernelGGL(k_trace_mfma32, dim3(grid), dim3(kMB), lds, stream, A, (const u32x4*)ctx->d_sph_frag32, mfma_blocks);
+        else if (tiled && levels == 4) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kTB), lds, stream, A, (const u32x4*)ctx->d_tri_sfrag, (const u32x4*)ctx->d_sph_sfrag);
         else if (tiled) hipLaunchKernelGGL(tiled, dim3(grid), dim3(kTB), lds, stream, A, (const u32x4*)(grouped ? ctx->d_tri_gfrag : ctx->d_tri_frag),
                                            (const u32x4*)(grouped ? ctx->d_sph_gfrag : (u32x4*)ctx->d_sph_frag32));
         else hipLaunchKernelGGL(plain, dim3(grid), dim3(kBlock), lds, stream, A);
@@ -973,7 +1020,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     ctx->last_samples = (uint64_t)npix * sample_count;
     ctx->last_was_path = true;
     ctx->last_mfma16 = tiled != nullptr || (mfma_single && !single_k64);
-    ctx->last_filter_rows = tiled ? (uint64_t)A.n_tri_rows + A.n_sph_rows : mfma_single ? ctx->n_sph : 0;
+    ctx->last_filter_rows = levels ? (uint64_t)(has_tri ? A.n_tri_top : 0u) + (has_sph ? A.n_sph_top : 0u) : tiled ? (uint64_t)A.n_tri_rows + A.n_sph_rows : mfma_single ? ctx->n_sph : 0;
     ctx->rendered = true;
     ctx->acc_valid = true; ctx->acc_params = *p; ctx->acc_cam = *cam; ctx->acc_done = sample_begin + sample_count; ctx->acc_npix = npix;
     return 0;

@@ -134,9 +134,10 @@ def test_tiled_rows_equal_resident_rows(rt3, renderer, seed, n_faces, n_sph, mon
         renderer.force_brute(False)
 
 
-def test_scene_beyond_the_resident_limit_streams_its_rows(rt3, renderer):
-    """150 000 spheres + 3 000 faces: 2 344 + 47 rows of 64, more than LDS holds (56 row blocks of 16): the default path is the tiled
-    multi-level filter.  Against the flat filter and the unfiltered kernel on a small frame."""
+def test_scene_beyond_three_levels_scans_super_rows(rt3, renderer):
+    """150 000 spheres + 3 000 faces: 2 344 + 47 rows of 64 are more than LDS holds beside the pair lists, so the filter takes FOUR levels — the matrix
+    cores scan super-rows of 512 primitives (294 + 6), a candidate super-row's 8 rows are tested in f32, then leaves, then members.  Against the flat
+    filter and the unfiltered kernel on a small frame."""
     cr, mats = rt3.scene_stress(150000, 9)
     rng = np.random.default_rng(31)
     faces, verts, fm, _, _ = random_soup(rng, 3000, 0, 1.0, rt3)
@@ -147,4 +148,75 @@ def test_scene_beyond_the_resident_limit_streams_its_rows(rt3, renderer):
                 params=dict(width=96, height=54, spp=2, max_depth=8, seed=3, flags=1))
     grouped, flat, brute, st_g, st_f = three_ways(renderer, case)
     assert np.array_equal(flat, brute) and np.array_equal(grouped, brute)
-    assert st_g.filter_tests // st_g.ray_casts > 56 * 16 and st_g.filter_tests * 50 < st_f.filter_tests
+    rows = st_g.filter_tests // st_g.ray_casts
+    assert rows == -(-2344 // 8) + -(-47 // 8) and st_g.filter_tests * 400 < st_f.filter_tests
+
+
+@pytest.mark.parametrize("levels,tiles", [("3", False), ("4", False), ("3", True), ("4", True)])
+@pytest.mark.parametrize("seed,n_faces,n_sph", [(41, 1100, 0), (42, 0, 1300), (43, 900, 800)])
+def test_three_and_four_levels_resident_and_tiled_give_the_same_frame(rt3, renderer, seed, n_faces, n_sph, levels, tiles, monkeypatch):
+    """k_trace_levels in all four forms on the same small soups (RT3_LEVELS forces the level count, RT3_NO_RESIDENT the tiles): the frame of the
+    unfiltered kernel every time, the same ray casts; with four levels the matrix cores scan an eighth of the rows."""
+    rng = np.random.default_rng(seed)
+    faces, verts, fm, cr, sm = random_soup(rng, n_faces, n_sph, 1.0, rt3)
+    cam = rt3.Camera().update(96, 64, 1.0, 3.0, 2.0)
+    case = dict(cam=cam.c, params=dict(width=96, height=64, spp=4, max_depth=6, seed=seed, flags=1, t_min=0.001))
+    if n_faces:
+        case.update(faces=faces, verts=verts, fmats=fm)
+    if n_sph:
+        case.update(spheres=cr, smats=sm)
+    want = hip_render(renderer, case)
+    st_d = renderer.stats()
+    monkeypatch.setenv("RT3_LEVELS", levels)
+    if tiles:
+        monkeypatch.setenv("RT3_NO_RESIDENT", "1")
+    got = hip_render(renderer, case, upload=False)
+    st = renderer.stats()
+    assert np.array_equal(got, want) and st.ray_casts == st_d.ray_casts
+    rows64 = -(-n_faces // 64) + -(-n_sph // 64)
+    per_cast = st.filter_tests // st.ray_casts
+    assert per_cast <= (rows64 if levels == "3" else -(-rows64 // 8)) + 4
+    monkeypatch.delenv("RT3_LEVELS")
+    monkeypatch.delenv("RT3_NO_RESIDENT", raising=False)
+    renderer.force_brute(True)
+    try:
+        assert np.array_equal(hip_render(renderer, case, upload=False), want)
+    finally:
+        renderer.force_brute(False)
+
+
+def test_nested_form_of_round_three_still_agrees(rt3, renderer, monkeypatch):
+    """RT3_OLD_GROUPS=1: k_trace_mfma_tiled's nested three-level form (the A/B reference of k_trace_levels)."""
+    rng = np.random.default_rng(51)
+    faces, verts, fm, cr, sm = random_soup(rng, 1000, 900, 1.0, rt3)
+    cam = rt3.Camera().update(96, 64, 1.0, 3.0, 2.0)
+    case = dict(faces=faces, verts=verts, fmats=fm, spheres=cr, smats=sm, cam=cam.c, params=dict(width=96, height=64, spp=4, max_depth=6, seed=5, flags=1, t_min=0.001))
+    want = hip_render(renderer, case)
+    monkeypatch.setenv("RT3_OLD_GROUPS", "1")
+    assert np.array_equal(hip_render(renderer, case, upload=False), want)
+
+
+@pytest.mark.parametrize("levels", ["3", "4", None])
+def test_scene_whose_spheres_are_all_direct_after_a_grouped_scene(rt3, renderer, levels, monkeypatch):
+    """A mesh with ONE sphere that every ray meets (the direct list takes it: no sphere rows at all), rendered on a context that held a large sphere
+    scene before — the row counts of the previous scene must not survive (regression: k_trace_levels read freed super-row fragments)."""
+    cr, mats = rt3.scene_stress(3000, 5)
+    cam = rt3.Camera().update(96, 64, 1.0, 3.0, 2.0)
+    renderer.set_mesh(np.zeros(0, rt3.GFACE), np.zeros((0, 4), np.float32))
+    renderer.set_spheres(cr, mats)
+    renderer.render_path(cam.c, rt3.make_params(96, 64, spp=1, max_depth=2, flags=1))
+    rng = np.random.default_rng(61)
+    faces, verts, fm, _, _ = random_soup(rng, 900, 0, 1.0, rt3)
+    one = np.float32([[0.0, -1000.0, -4.0, 999.0]])
+    sm = np.zeros(1, rt3.MATERIAL)
+    sm["kind"], sm["rgb"] = 1, (0.5, 0.5, 0.5)
+    case = dict(faces=faces, verts=verts, fmats=fm, spheres=one, smats=sm, cam=cam.c, params=dict(width=96, height=64, spp=2, max_depth=5, seed=6, flags=1, t_min=0.001))
+    if levels:
+        monkeypatch.setenv("RT3_LEVELS", levels)
+    got = hip_render(renderer, case)
+    monkeypatch.delenv("RT3_LEVELS", raising=False)
+    renderer.force_brute(True)
+    try:
+        assert np.array_equal(hip_render(renderer, case, upload=False), got)
+    finally:
+        renderer.force_brute(False)

@@ -101,7 +101,17 @@ def run(count, first, r=None, log=print):
         if bad:
             bad_total += 1
             log("seed %d: %d pixels differ  %r" % (seed, bad, info))
-        if seed % 5 == 0:                                            # the same rows streamed through LDS tiles (the path of scenes > 114 000 primitives)
+        if seed % 7 in (0, 1, 2):                                    # k_trace_levels (the kernel of scenes > 114 000 primitives) in three of its forms
+            os.environ["RT3_LEVELS"] = "4" if seed % 7 != 2 else "3"
+            if seed % 7 == 1:
+                os.environ["RT3_NO_RESIDENT"] = "1"
+            lev = r.render_path(cam.c, p)
+            del os.environ["RT3_LEVELS"]
+            os.environ.pop("RT3_NO_RESIDENT", None)
+            if (lev != ref).any():
+                bad_total += 1
+                log("seed %d: K_TRACE_LEVELS (seed %% 7 = %d) %d pixels differ  %r" % (seed, seed % 7, int((lev != ref).sum()), info))
+        if seed % 5 == 0:                                            # the nested form with its rows streamed through LDS tiles
             os.environ["RT3_NO_RESIDENT"] = "1"
             tiled = r.render_path(cam.c, p)
             del os.environ["RT3_NO_RESIDENT"]
