@@ -65,6 +65,7 @@ struct rt3_ctx {
     u32x4* d_sph_gfrag = nullptr; float4* d_sph_grp = nullptr; uint32_t* d_sph_perm = nullptr; uint32_t n_sph_groups = 0;
     float4* d_tri_leaf = nullptr; float4* d_sph_leaf = nullptr; uint32_t n_tri_leaves = 0, n_sph_leaves = 0;      // three-level filter: the leaf groups' bounds
     float4* d_tri_rowb = nullptr; float4* d_sph_rowb = nullptr;    // ... and the rows' own bounds in f32 (rows behind a ray are dropped before their leaves are tested)
+    float4* d_tri_rec = nullptr;                                   // the faces' records in group order (the exact test of the multi-level filter reads these)
     u32x4* d_tri_sfrag = nullptr; u32x4* d_sph_sfrag = nullptr; float4* d_tri_srowb = nullptr; float4* d_sph_srowb = nullptr;   // four levels: super-rows of kSuper rows
     uint32_t n_tri_super = 0, n_sph_super = 0;
     uint32_t* d_strips = nullptr; size_t strip_entries = 0;          // deferred member tests: kStripPairs pairs per wave of the grid
@@ -442,7 +443,7 @@ void rt3_destroy(rt3_ctx* ctx) {
     void* bufs[] = { ctx->d_gfaces, ctx->d_verts, ctx->d_face_mats_in, ctx->d_error, ctx->d_tri, ctx->d_tri_mat, ctx->d_tri_kind, ctx->d_tri_bound, ctx->d_tri_frag, ctx->d_sph, ctx->d_sph_frag, ctx->d_sph_frag32, ctx->d_sph_invr, ctx->d_sph_mat, ctx->d_sph_kind,
                      ctx->d_rad, ctx->d_accum, ctx->d_accum_sq, ctx->d_out, ctx->d_work, ctx->d_casts, ctx->d_box, ctx->d_tri_frag_r,
                      ctx->d_tri_gfrag, ctx->d_sph_gfrag, ctx->d_sph_grp, ctx->d_sph_perm, ctx->d_strips, ctx->d_tri_grp, ctx->d_tri_perm, ctx->d_tri_leaf, ctx->d_sph_leaf, ctx->d_tri_rowb, ctx->d_sph_rowb,
-                     ctx->d_tri_sfrag, ctx->d_sph_sfrag, ctx->d_tri_srowb, ctx->d_sph_srowb };
+                     ctx->d_tri_sfrag, ctx->d_sph_sfrag, ctx->d_tri_srowb, ctx->d_sph_srowb, ctx->d_tri_rec };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& p : ctx->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -519,7 +520,7 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
     RT3_HIP(hipSetDevice(ctx->device));
     const uint32_t n = ctx->cap_gfaces, n_pad = (n + 3u) / 4u * 4u;
     for (void** b : { (void**)&ctx->d_tri, (void**)&ctx->d_tri_mat, (void**)&ctx->d_tri_kind, (void**)&ctx->d_tri_bound, (void**)&ctx->d_tri_frag, (void**)&ctx->d_face_mats_in,
-                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm, (void**)&ctx->d_tri_leaf, (void**)&ctx->d_tri_rowb, (void**)&ctx->d_tri_sfrag, (void**)&ctx->d_tri_srowb })
+                      (void**)&ctx->d_tri_frag_r, (void**)&ctx->d_tri_gfrag, (void**)&ctx->d_tri_grp, (void**)&ctx->d_tri_perm, (void**)&ctx->d_tri_leaf, (void**)&ctx->d_tri_rowb, (void**)&ctx->d_tri_sfrag, (void**)&ctx->d_tri_srowb, (void**)&ctx->d_tri_rec })
         if (*b) { RT3_HIP(hipFree(*b)); *b = nullptr; }
     ctx->n_faces = 0; ctx->n_tri_groups = 0; ctx->n_tri_super = 0;
     if (n == 0) return 0;
@@ -578,6 +579,10 @@ int rt3_mesh_commit(rt3_ctx* ctx, const rt3_material* face_materials) {
         for (size_t k = 0; k < order.size(); k++) if (order[k] != 0xFFFFFFFFu) grp[k] = bounds[order[k]];
         int rc;
         if ((rc = upload(ctx, &ctx->d_tri_grp, grp)) || (rc = upload(ctx, &ctx->d_tri_perm, order))) return rc;
+        RT3_HIP(hipMalloc((void**)&ctx->d_tri_rec, order.size() * 4 * sizeof(float4)));
+        hipLaunchKernelGGL(k_gather_face_records, dim3(((uint32_t)order.size() * 4u + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->d_tri,
+                           (const uint32_t*)ctx->d_tri_perm, (uint32_t)order.size(), ctx->d_tri_rec);
+        RT3_HIP(hipGetLastError());
         ctx->n_tri_leaves = (uint32_t)(order.size() / kGroupTri);
         ctx->n_tri_groups = ctx->n_tri_leaves / kSuper;                // rows the matrix filter scans
         const float4* row_members = ctx->d_tri_grp;
@@ -907,7 +912,7 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
     const bool grouped = kGroupTri > 1 && kGroupSph > 1 && !ctx->force_flat && !getenv("RT3_NO_GROUPS");
     A.n_tri_rows = grouped ? ctx->n_tri_groups : ctx->n_faces;
     A.n_sph_rows = grouped ? ctx->n_sph_groups : ctx->n_sph;
-    A.sph_grp = ctx->d_sph_grp; A.sph_perm = ctx->d_sph_perm; A.tri_grp = ctx->d_tri_grp; A.tri_perm = ctx->d_tri_perm;
+    A.sph_grp = ctx->d_sph_grp; A.sph_perm = ctx->d_sph_perm; A.tri_grp = ctx->d_tri_grp; A.tri_perm = ctx->d_tri_perm; A.tri_rec = ctx->d_tri_rec;
     A.tri_leaf = ctx->d_tri_leaf; A.sph_leaf = ctx->d_sph_leaf; A.n_tri_leaves = ctx->n_tri_leaves; A.n_sph_leaves = ctx->n_sph_leaves;
     A.tri_rowb = ctx->d_tri_rowb; A.sph_rowb = ctx->d_sph_rowb;
     const uint32_t mfma_blocks = (ctx->n_sph + 31u) / 32u;

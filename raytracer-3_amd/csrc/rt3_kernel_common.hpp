@@ -139,6 +139,7 @@ struct TraceArgs {
     // candidate row's rays are tested against in f32 before the leaves' members are.  n_*_leaves: leaf groups (= rows x kSuper).
     const float4* sph_leaf; const float4* tri_leaf; uint32_t n_sph_leaves, n_tri_leaves;
     const float4* sph_rowb; const float4* tri_rowb;                 // three-level filter: the rows' own bounds (C, R_eff^2) in f32, or null
+    const float4* tri_rec;                                          // the faces' 64-byte records once more, in GROUP order (a leaf's 8 faces: 512 contiguous bytes)
     const float4* sph_topb; const float4* tri_topb; uint32_t n_sph_top, n_tri_top;   // k_trace_levels: what the matrix cores scan (rows, or super-rows of 8 rows) and its bounds in f32
     uint32_t* pair_strips;   // [wave of the grid][kStripPairs]: candidate (ray lane, row) pairs set aside for the end of a pass (deferred member tests)
     uint32_t* work_counter;

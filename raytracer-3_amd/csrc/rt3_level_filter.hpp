@@ -215,18 +215,18 @@ __global__ __launch_bounds__(kTB) void k_trace_levels(const TraceArgs A, const u
         };
 
         if constexpr (HAS_TRI) {
-            auto face_test = [&](uint32_t pair, bool valid) {                  // the reference's plane + three-edge test of (ray lane, face) pairs
-                const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
+            auto face_test = [&](uint32_t pair, bool valid) {                  // the reference's plane + three-edge test of (ray lane, face position) pairs
+                const uint32_t src = pair >> kPairLaneShift, pos = pair & ((1u << kPairLaneShift) - 1u);
                 const LaneRay r = fetch_ray<REF>(ray, src);
                 exact += (unsigned long long)__popcll(__ballot(valid));
-                if (!valid || j >= A.n_tri) return;
-                const float4* f = A.tri + (size_t)j * 4;
+                if (!valid) return;
+                const float4* f = A.tri_rec + (size_t)pos * 4;                    // the record in group order: a leaf's faces share cache lines
                 const float4 n = f[0], p1 = f[1], p2 = f[2], p3 = f[3];
                 const float t_hi = __uint_as_float((uint32_t)(keys[src] >> 32));   // the ray's best t so far: farther faces need no edge tests
                 float t;
                 if (!face_t(n, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.literal, t) || !(t >= A.t_min && t <= t_hi)) return;
                 if (!face_inside(n, p1, p2, p3, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t)) return;
-                if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
+                if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, A.tri_perm[pos]));      // the key carries the face's own index
             };
             auto face_members = [&](uint32_t pair, bool valid, uint32_t part) {  // a leaf's faces: their own bounds (margin 1e-5 c, as the VALU kernels')
                 const uint32_t src = pair >> kPairLaneShift, g = pair & ((1u << kPairLaneShift) - 1u);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kTB) void k_trace_levels(const TraceArgs A, const u
                     const bool behind = (h < 0.0f) & (c > 2e-3f * b[m].w);
                     // a face without a bounded hit region (r^2 = 3e38, possibly a non-finite centre) goes to the exact test whatever the arithmetic made of it
                     keep[m] = ok && (((__float_as_uint(disc) >> 31) == 0u && !behind) || b[m].w >= 3e38f);
-                    value[m] = keep[m] ? A.tri_perm[p0 + m] : 0u;
+                    value[m] = p0 + m;
                 }
                 push4(keep, src, value, fpairs, n_f);
             };

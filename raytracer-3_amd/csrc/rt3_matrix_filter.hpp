@@ -1154,18 +1154,20 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
             RT3_PHASE(pt_test)
         };
         if (HAS_TRI) {
-            auto face_test = [&](uint32_t pair, bool valid) {                  // the reference's plane + three-edge test of (ray lane, face) pairs
+            // the reference's plane + three-edge test of (ray lane, face) pairs.  GT == 1: the pair names the face; GT > 1: its POSITION in group order —
+            // the record is read from A.tri_rec (a leaf's 8 faces: 512 contiguous bytes) and the face's own index, which the key carries, only on a hit
+            auto face_test = [&](uint32_t pair, bool valid) {
                 const uint32_t src = pair >> kPairLaneShift, j = pair & ((1u << kPairLaneShift) - 1u);
                 const LaneRay r = fetch_ray<REF>(ray, src);
                 exact += (unsigned long long)__popcll(__ballot(valid));
-                if (!valid || j >= A.n_tri) return;
-                const float4* f = A.tri + (size_t)j * 4;
+                if (!valid || (GT == 1 && j >= A.n_tri)) return;
+                const float4* f = (GT == 1 ? A.tri : A.tri_rec) + (size_t)j * 4;
                 const float4 n = f[0], p1 = f[1], p2 = f[2], p3 = f[3];           // the whole 64-byte record at once: ONE trip to L2, not two
                 const float t_hi = __uint_as_float((uint32_t)(keys[src] >> 32));   // the ray's best t so far: farther faces need no edge tests
                 float t;
                 if (!face_t(n, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.literal, t) || !(t >= A.t_min && t <= t_hi)) return;
                 if (!face_inside(n, p1, p2, p3, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t)) return;
-                if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, j));
+                if (t < __builtin_inff()) atomicMin(&keys[src], hit_key(t, 0u, GT == 1 ? j : A.tri_perm[j]));
             };
             if constexpr (GT == 1) {
                 pass(tri_frags, A.n_tri_rows, (const float4*)nullptr, std::false_type(), std::bool_constant<RT3_FACE_K32 != 0>(), std::integral_constant<uint32_t, 1>(), face_test,
@@ -1200,7 +1202,7 @@ __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, con
 #endif
                         const unsigned long long km = __ballot(keep);
                         if (km == 0ull) continue;
-                        if (keep) fpairs[n_fpairs + prefix_count(km)] = (src << kPairLaneShift) | A.tri_perm[p0 + m];
+                        if (keep) fpairs[n_fpairs + prefix_count(km)] = (src << kPairLaneShift) | (p0 + m);
                         n_fpairs += (uint32_t)__popcll(km);
                         __builtin_amdgcn_wave_barrier();
                         if (n_fpairs >= 64u) {

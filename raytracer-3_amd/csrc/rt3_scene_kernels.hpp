@@ -251,6 +251,14 @@ __device__ __forceinline__ float4 group_bound(const float4* __restrict__ bounds,
     if ((double)r2f < r2) r2f = __uint_as_float(__float_as_uint(r2f) + 1u);
     return make_float4(fcx, fcy, fcz, r2f);
 }
+// The faces' exact-test records (4 x float4) in group order: rec[4 k ..] = tri[4 perm[k] ..]; positions without a face (padding) get zeros — their
+// bound is a never-candidate, nothing reads them.
+__global__ void k_gather_face_records(const float4* __restrict__ tri, const uint32_t* __restrict__ perm, uint32_t n_pos, float4* __restrict__ rec) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pos * 4u) return;
+    const uint32_t j = perm[i >> 2];
+    rec[i] = j == 0xFFFFFFFFu ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : tri[(size_t)j * 4u + (i & 3u)];
+}
 // The groups' bounds as records (three-level filter: the leaves' spheres, which the middle level tests in f32).
 __global__ void k_group_bounds(const float4* __restrict__ bounds, uint32_t n_entries, uint32_t group, uint32_t n_groups, const uint32_t* __restrict__ box,
                                float ecx, float ecy, float ecz, float4* __restrict__ out) {
