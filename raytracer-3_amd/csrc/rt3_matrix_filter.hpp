@@ -1,5 +1,6 @@
 // rt3_matrix_filter.hpp — the candidate filter on the matrix cores and its kernels: k_trace_mfma32 (scenes of <= 512 spheres: the bench
-// kernel), k_trace_mfma_tiled (every other scene), k_mode_r_mfma (Mode R), k_trace_mfma (round 1's K = 64 kernel, the A/B reference).
+// kernel), k_trace_mfma_tiled (every other scene up to 114 000 primitives; beyond: k_trace_levels, rt3_level_filter.hpp), k_mode_r_mfma (Mode R),
+// k_trace_mfma (round 1's K = 64 kernel, the A/B reference).
 // Order of the file: the K = 64 form on v_mfma_f32_32x32x16_bf16 (the derivation; k_trace_mfma only), its 16x16x32 variant (A/B reference
 // for faces), the K = 32 form on v_mfma_f32_16x16x32_bf16 that every default kernel runs, the pair list, the kernels.
 // Part of rt3_device.hip (one translation unit, gfx950 only); included from there, in this order.
