@@ -168,6 +168,8 @@ __global__ __launch_bounds__(kTB) void k_trace_levels(const TraceArgs A, const u
                 __builtin_amdgcn_wave_barrier();
             };
             if (n_strip != 0u) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the strip was written by other lanes of this wave
+            bool have_next = false;
+            uint32_t next_pr = 0u;
             for (;;) {
                 const bool dry = spos >= n_strip;                                  // nothing left above the lists
                 if (n_f >= 64u || (final && n_f != 0u && n_l == 0u && n_s == 0u && dry)) exact_batch();
@@ -176,8 +178,11 @@ __global__ __launch_bounds__(kTB) void k_trace_levels(const TraceArgs A, const u
                 else if (!dry) {
                     const uint32_t take = min(n_strip - spos, PER);
                     const bool v = lane / LPP < take;
-                    const uint32_t pr = strip[spos + (v ? lane / LPP : 0u)];
+                    if (!have_next) next_pr = strip[min(spos + lane / LPP, n_strip - 1u)];
+                    const uint32_t pr = next_pr;
                     spos += take;
+                    have_next = spos < n_strip;                                    // the following batch's pairs: in flight while this one is tested
+                    if (have_next) next_pr = strip[min(spos + lane / LPP, n_strip - 1u)];
                     if constexpr (LEVELS == 4) expand(pr, v, lane % LPP, rowb, n_top, beyond_tag, spairs, n_s);
                     else expand(pr, v, lane % LPP, leafb, n_rows, beyond_tag, lpairs, n_l);
                     __builtin_amdgcn_wave_barrier();
