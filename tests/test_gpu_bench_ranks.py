@@ -47,3 +47,20 @@ def test_ranks_on_one_gpu_render_their_shards_and_gather_the_one_rank_frame(tmp_
         assert key in many
     assert many["value"] > 0 and many["scaling"] == "strong" and "REHEARSAL" in many["config"]["sharding"]
     assert "cpu_baseline" not in many                                         # rank 0 at N = 1 only
+
+
+def test_rccl_gather_path_with_one_rank(tmp_path):
+    """RT3_BENCH_FORCE_DIST=1: one rank under torch.distributed.run with backend "nccl" (RCCL) — process-group initialisation with device_id,
+    dist.gather of the tile on the render's stream, the indexed copy into the frame, the all_reduce of the statistics: the code an N-GPU run executes,
+    with N = 1 (two ranks cannot share the one GPU of the box under RCCL).  Same frame as the native world-1 path (rt3_gather_rows)."""
+    one = run_bench(1, tmp_path / "native.ppm")
+    common = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--spp", "8", "--cpu-seconds", "0", "--no-extra", "--save-ppm", str(tmp_path / "rccl.ppm")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + common
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", RT3_BENCH_FORCE_DIST="1")
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert (tmp_path / "rccl.ppm").read_bytes() == (tmp_path / "native.ppm").read_bytes()
+    assert d["n_gpus"] == 1 and "RCCL gather" in d["config"]["sharding"] and d["ray_casts"] == one["ray_casts"]
