@@ -937,8 +937,8 @@ int rt3_render_path_range_device(rt3_ctx* ctx, const rt3_camera* cam, const rt3_
         constexpr uint32_t GT = kGroupTri, GS = kGroupSph, SUP = kSuper;
         const uint32_t row_blocks = (has_tri ? (A.n_tri_rows + 31u) / 32u : 0u) + (has_sph ? (A.n_sph_rows + 31u) / 32u : 0u);
         const uint32_t super_blocks = (has_tri ? (ctx->n_tri_super + 31u) / 32u : 0u) + (has_sph ? (ctx->n_sph_super + 31u) / 32u : 0u);
-        // While the rows of 64 fit in LDS (<= kResidentBlocks row blocks, 114 000 primitives: both BASELINE scenes) k_trace_mfma_tiled's resident three-level
-        // form runs; beyond, k_trace_levels (rt3_level_filter.hpp) with FOUR levels — the matrix cores scan super-rows of 512, resident up to 590 000
+        // While the rows of 64 fit in LDS (<= kResidentBlocks row blocks, 112 000 primitives: both BASELINE scenes) k_trace_mfma_tiled's resident three-level
+        // form runs; beyond, k_trace_levels (rt3_level_filter.hpp) with FOUR levels — the matrix cores scan super-rows of 512, resident up to 570 000
         // primitives, through a tile after that.  RT3_LEVELS=3|4 forces k_trace_levels with that many levels, RT3_OLD_GROUPS=1 the nested form (A/B, tests)
         const char* force_levels = getenv("RT3_LEVELS");
         const bool no_res_env = getenv("RT3_NO_RESIDENT") != nullptr;

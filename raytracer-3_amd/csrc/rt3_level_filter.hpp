@@ -14,7 +14,7 @@
 // parents: 64 KiB of LDS for the four lists of 16 waves).  Smaller lists with a make-room branch in every stage were built and measured 8-20 % slower (the
 // survivors' ballots and pushes in two phases); so were four levels on the BASELINE scenes (100 000 spheres x1.24, 47 106 faces x1.28: 8 row tests per
 // candidate super-row cost more than scanning 1 500 rows).  The host therefore keeps k_trace_mfma_tiled's resident three-level form while the rows of 64 fit
-// in LDS (<= 114 000 primitives) and runs this kernel with four levels beyond (300 000 spheres x0.95, 10^6 x0.83, 3 10^6 x0.64 against the tiled three-level
+// in LDS (<= 112 000 primitives) and runs this kernel with four levels beyond (300 000 spheres x0.95, 10^6 x0.83, 3 10^6 x0.64 against the tiled three-level
 // form).  Frames are k_trace_mfma_tiled's bit for bit: the nearest-hit key does not care in which order pairs are tested.
 #pragma once
 
@@ -31,7 +31,10 @@ __host__ __device__ constexpr size_t lev_lds_fixed(uint32_t levels, bool res) { 
     return (size_t)kTB * 8u + (size_t)(res ? kLevBmBlocks : kLevBmBlocksTiled) * kTB * 4u + (size_t)(kTB / 64u) * lev_list_words(levels) * 4u +
            (res ? 0u : (size_t)kTB * kLevTileLoads * 16u);
 }
-__host__ __device__ constexpr uint32_t lev_resident_blocks(uint32_t levels) { return (uint32_t)((160u * 1024u - lev_lds_fixed(levels, true)) / 2048u); }
+// (one block less than what fits: a request of exactly 160 KiB is refused by hipFuncSetAttribute)
+__host__ __device__ constexpr uint32_t lev_resident_blocks(uint32_t levels) { return (uint32_t)((160u * 1024u - lev_lds_fixed(levels, true)) / 2048u) - 1u; }
+static_assert(lev_lds_fixed(3, true) + lev_resident_blocks(3) * 2048u < 160u * 1024u && lev_lds_fixed(4, true) + lev_resident_blocks(4) * 2048u < 160u * 1024u &&
+              lev_lds_fixed(3, false) < 160u * 1024u && lev_lds_fixed(4, false) < 160u * 1024u, "k_trace_levels: LDS");
 
 template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t LEVELS, bool RES>
 __global__ __launch_bounds__(kTB) void k_trace_levels(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {

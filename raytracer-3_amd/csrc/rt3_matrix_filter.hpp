@@ -1,5 +1,5 @@
 // rt3_matrix_filter.hpp — the candidate filter on the matrix cores and its kernels: k_trace_mfma32 (scenes of <= 512 spheres: the bench
-// kernel), k_trace_mfma_tiled (every other scene up to 114 000 primitives; beyond: k_trace_levels, rt3_level_filter.hpp), k_mode_r_mfma (Mode R),
+// kernel), k_trace_mfma_tiled (every other scene up to 112 000 primitives; beyond: k_trace_levels, rt3_level_filter.hpp), k_mode_r_mfma (Mode R),
 // k_trace_mfma (round 1's K = 64 kernel, the A/B reference).
 // Order of the file: the K = 64 form on v_mfma_f32_32x32x16_bf16 (the derivation; k_trace_mfma only), its 16x16x32 variant (A/B reference
 // for faces), the K = 32 form on v_mfma_f32_16x16x32_bf16 that every default kernel runs, the pair list, the kernels.
@@ -972,7 +972,8 @@ constexpr uint32_t kGroupTri = RT3_GROUP_TRI, kGroupSph = RT3_GROUP_SPH, kSuper 
 // fill and no barrier after the prologue, the 16 waves of the workgroup run free as k_trace_mfma32's do (each leaves when its own paths are done).
 // The host picks it when the rows fit (kResidentBlocks); the candidate words then cover kBmBlocksRes row blocks per push.
 constexpr uint32_t kBmBlocksRes = 4;
-constexpr uint32_t kResidentBlocks = (160u * 1024u - kTB * 8u - (kTB / 64u) * kPairCap * 4u * 3u - kBmBlocksRes * kTB * 4u) / 2048u;      // row blocks of 2 KiB: 56
+constexpr uint32_t kResidentBlocks = (160u * 1024u - kTB * 8u - (kTB / 64u) * kPairCap * 4u * 3u - kBmBlocksRes * kTB * 4u) / 2048u - 1u;   // row blocks of 2 KiB: 55
+// (one less than what fits: a request of exactly 160 KiB is refused by hipFuncSetAttribute)
 template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t GT = 1, uint32_t GS = 1, uint32_t SUP = 1, bool RES = false>
 __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     static_assert(64 % GT == 0 && 64 % GS == 0, "group sizes must divide the wave");

@@ -111,7 +111,7 @@ def test_environment_switch_selects_the_flat_filter(renderer, name, monkeypatch)
 @pytest.mark.parametrize("seed,n_faces,n_sph", [(21, 900, 0), (22, 0, 1100), (23, 1301, 707)])
 def test_tiled_rows_equal_resident_rows(rt3, renderer, seed, n_faces, n_sph, monkeypatch):
     """Scenes whose rows fit in LDS run the barrier-free variant; RT3_NO_RESIDENT=1 streams the same rows through the 64-KiB tiles (the path
-    of scenes beyond 114 000 primitives): same frame, same counters."""
+    of scenes beyond 112 000 primitives): same frame, same counters."""
     rng = np.random.default_rng(seed)
     faces, verts, fm, cr, sm = random_soup(rng, n_faces, n_sph, 1.0, rt3)
     cam = rt3.Camera().update(96, 64, 1.0, 3.0, 2.0)
@@ -220,3 +220,21 @@ def test_scene_whose_spheres_are_all_direct_after_a_grouped_scene(rt3, renderer,
         assert np.array_equal(hip_render(renderer, case, upload=False), got)
     finally:
         renderer.force_brute(False)
+
+
+@pytest.mark.parametrize("n", [112600, 112700, 114700])
+def test_sphere_counts_around_the_resident_limit_launch(rt3, renderer, n):
+    """55 row blocks of 32 rows of 64 spheres = 112 640 spheres is the most the resident three-level form takes (one block more is exactly 160 KiB of LDS,
+    which the runtime refuses); the next sphere moves the scene to k_trace_levels.  Both sides of the limit must launch and agree with the flat filter."""
+    cr, mats = rt3.scene_stress(n, 3)
+    cam = rt3.Camera().look_at(64, 36, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
+    case = dict(spheres=cr, smats=mats, cam=cam.c, params=dict(width=64, height=36, spp=1, max_depth=4, seed=3, flags=1))
+    grouped = hip_render(renderer, case)
+    st = renderer.stats()
+    renderer.force_flat_filter(True)
+    try:
+        assert np.array_equal(hip_render(renderer, case, upload=False), grouped)
+    finally:
+        renderer.force_flat_filter(False)
+    rows = st.filter_tests // st.ray_casts
+    assert rows == (-(-n // 64) if n <= 112640 else -(-(-(-n // 64)) // 8))

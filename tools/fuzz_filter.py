@@ -101,7 +101,7 @@ def run(count, first, r=None, log=print):
         if bad:
             bad_total += 1
             log("seed %d: %d pixels differ  %r" % (seed, bad, info))
-        if seed % 7 in (0, 1, 2):                                    # k_trace_levels (the kernel of scenes > 114 000 primitives) in three of its forms
+        if seed % 7 in (0, 1, 2):                                    # k_trace_levels (the kernel of scenes > 112 000 primitives) in three of its forms
             os.environ["RT3_LEVELS"] = "4" if seed % 7 != 2 else "3"
             if seed % 7 == 1:
                 os.environ["RT3_NO_RESIDENT"] = "1"
