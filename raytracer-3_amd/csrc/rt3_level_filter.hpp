@@ -31,7 +31,7 @@ __host__ __device__ constexpr size_t lev_lds_fixed(uint32_t levels, bool res) { 
     return (size_t)kTB * 8u + (size_t)(res ? kLevBmBlocks : kLevBmBlocksTiled) * kTB * 4u + (size_t)(kTB / 64u) * lev_list_words(levels) * 4u +
            (res ? 0u : (size_t)kTB * kLevTileLoads * 16u);
 }
-// (one block less than what fits: a request of exactly 160 KiB is refused by hipFuncSetAttribute)
+// (one block of headroom: a kernel with any static LDS beside the dynamic request — __syncthreads_or's word, say — is refused at exactly 160 KiB)
 __host__ __device__ constexpr uint32_t lev_resident_blocks(uint32_t levels) { return (uint32_t)((160u * 1024u - lev_lds_fixed(levels, true)) / 2048u) - 1u; }
 static_assert(lev_lds_fixed(3, true) + lev_resident_blocks(3) * 2048u < 160u * 1024u && lev_lds_fixed(4, true) + lev_resident_blocks(4) * 2048u < 160u * 1024u &&
               lev_lds_fixed(3, false) < 160u * 1024u && lev_lds_fixed(4, false) < 160u * 1024u, "k_trace_levels: LDS");

@@ -973,7 +973,8 @@ constexpr uint32_t kGroupTri = RT3_GROUP_TRI, kGroupSph = RT3_GROUP_SPH, kSuper 
 // The host picks it when the rows fit (kResidentBlocks); the candidate words then cover kBmBlocksRes row blocks per push.
 constexpr uint32_t kBmBlocksRes = 4;
 constexpr uint32_t kResidentBlocks = (160u * 1024u - kTB * 8u - (kTB / 64u) * kPairCap * 4u * 3u - kBmBlocksRes * kTB * 4u) / 2048u - 1u;   // row blocks of 2 KiB: 55
-// (one less than what fits: a request of exactly 160 KiB is refused by hipFuncSetAttribute)
+// (one block of headroom: a kernel with any static LDS beside the dynamic request — __syncthreads_or's word, say — is refused at exactly 160 KiB;
+// this variant has none and did launch with 56, profiles/README.md)
 template <bool HAS_TRI, bool HAS_SPH, bool REF, uint32_t GT = 1, uint32_t GS = 1, uint32_t SUP = 1, bool RES = false>
 __global__ __launch_bounds__(kTB) void k_trace_mfma_tiled(const TraceArgs A, const u32x4* __restrict__ tri_frags, const u32x4* __restrict__ sph_frags) {
     static_assert(64 % GT == 0 && 64 % GS == 0, "group sizes must divide the wave");

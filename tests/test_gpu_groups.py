@@ -224,8 +224,8 @@ def test_scene_whose_spheres_are_all_direct_after_a_grouped_scene(rt3, renderer,
 
 @pytest.mark.parametrize("n", [112600, 112700, 114700])
 def test_sphere_counts_around_the_resident_limit_launch(rt3, renderer, n):
-    """55 row blocks of 32 rows of 64 spheres = 112 640 spheres is the most the resident three-level form takes (one block more is exactly 160 KiB of LDS,
-    which the runtime refuses); the next sphere moves the scene to k_trace_levels.  Both sides of the limit must launch and agree with the flat filter."""
+    """55 row blocks of 32 rows of 64 spheres = 112 640 spheres is the most the resident three-level form takes (one block of headroom below 160 KiB of
+    LDS); the next sphere moves the scene to k_trace_levels.  Both sides of the limit must launch and agree with the flat filter."""
     cr, mats = rt3.scene_stress(n, 3)
     cam = rt3.Camera().look_at(64, 36, (0.0, 8.0, 12.0), (0.0, 6.0, -50.0), (0.0, 1.0, 0.0), 45.0, 1.0)
     case = dict(spheres=cr, smats=mats, cam=cam.c, params=dict(width=64, height=36, spp=1, max_depth=4, seed=3, flags=1))
